@@ -1,0 +1,247 @@
+"""CPU restatement of the IndexTTS2 autoregressive GPT path (fp32).  TEST INFRASTRUCTURE ONLY.
+
+Rows G0-G9 of SURVEY.md section 8(a).  Reference files (relative to the reference root):
+  indextts/gpt/model_v2.py:90-212      GPT2InferenceModel (prepare_inputs / forward / reorder)
+  indextts/gpt/model_v2.py:554-661     UnifiedVoice.forward (latent pass), prepare_gpt_inputs
+  indextts/gpt/model_v2.py:663-734     inference_speech
+  indextts/gpt/transformers_gpt2.py:129-348,464-568,571-667,985-1184   GPT-2 trunk (text twin
+      of third-party transformers==4.52.1, pyproject.toml:58)
+  indextts/gpt/transformers_generation_utils.py:843-1070,3123-3297      processors, _sample
+
+Weights are a flat dict keyed like `UnifiedVoice.state_dict()`:
+  gpt.h.{i}.ln_1.{weight,bias}  gpt.h.{i}.attn.c_attn.{weight[D,3D],bias}
+  gpt.h.{i}.attn.c_proj.{weight[D,D],bias}  gpt.h.{i}.ln_2.*  gpt.h.{i}.mlp.c_fc.{weight[D,4D],bias}
+  gpt.h.{i}.mlp.c_proj.{weight[4D,D],bias}  gpt.ln_f.*  final_norm.*  mel_head.{weight[V,D],bias}
+  mel_embedding.weight  mel_pos_embedding.emb.weight  text_embedding.weight
+  text_pos_embedding.emb.weight  speed_emb.weight
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+NEG = torch.finfo(torch.float32).min
+
+
+def layer_norm(x, w, b, eps=1e-5):
+    """nn.LayerNorm(eps=1e-5) (transformers_gpt2.py:598-600,1164; model_v2.py:398)."""
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def gelu_new(x):
+    """ACT2FN['gelu_new'] (config default activation_function; transformers_gpt2.py:571-585)."""
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
+
+
+class GptOracle:
+    def __init__(self, W, n_layer, n_head):
+        self.W = {k: torch.as_tensor(v, dtype=torch.float32) for k, v in W.items() if k.startswith(("gpt.", "final_norm", "mel_", "text_", "speed_emb"))}
+        self.L = n_layer
+        self.H = n_head
+        self.D = self.W["gpt.ln_f.weight"].shape[0]
+        self.dh = self.D // n_head
+
+    # ------------------------------------------------------------------ trunk
+    def trunk(self, emb, past=None, key_mask=None):
+        """GPT2Model.forward with inputs_embeds, wpe == 0 (model_v2.py:22-23,272-274).
+
+        emb [B,T,D]; past: list of (k,v) each [B,H,S,dh] or None; key_mask [B,S+T] of 0/1
+        (HF attention_mask; None == all ones).  Returns (ln_f(h) [B,T,D], new past).
+
+        Attention = softmax(q k^T / sqrt(dh) + causal + padding) v with the additive
+        finfo.min mask of _prepare_4d_causal_attention_mask_for_sdpa
+        (transformers_gpt2.py:1045-1051, 531-558).
+        """
+        W, H, dh = self.W, self.H, self.dh
+        B, T, D = emb.shape
+        S = 0 if past is None else past[0][0].shape[2]
+        # query row i (absolute position S+i) may see key j iff j <= S+i and key_mask[j]==1
+        qpos = torch.arange(S, S + T).view(T, 1)
+        kpos = torch.arange(S + T).view(1, S + T)
+        allow = (kpos <= qpos).view(1, 1, T, S + T)
+        if key_mask is not None:
+            allow = allow & (torch.as_tensor(key_mask).view(B, 1, 1, S + T) != 0)
+        add_mask = torch.zeros(allow.shape, dtype=torch.float32).masked_fill(~allow, NEG)
+        h = emb
+        new_past = []
+        for i in range(self.L):
+            p = f"gpt.h.{i}."
+            a = layer_norm(h, W[p + "ln_1.weight"], W[p + "ln_1.bias"])
+            qkv = a @ W[p + "attn.c_attn.weight"] + W[p + "attn.c_attn.bias"]  # Conv1D: x@W+b
+            q, k, v = qkv.split(D, dim=-1)
+            q = q.view(B, T, H, dh).transpose(1, 2)
+            k = k.view(B, T, H, dh).transpose(1, 2)
+            v = v.view(B, T, H, dh).transpose(1, 2)
+            if past is not None:
+                k = torch.cat((past[i][0], k), dim=2)
+                v = torch.cat((past[i][1], v), dim=2)
+            new_past.append((k, v))
+            sc = (q @ k.transpose(-1, -2)) / math.sqrt(dh) + add_mask
+            att = torch.softmax(sc, dim=-1) @ v
+            att = att.transpose(1, 2).reshape(B, T, D)
+            h = h + (att @ W[p + "attn.c_proj.weight"] + W[p + "attn.c_proj.bias"])
+            m = layer_norm(h, W[p + "ln_2.weight"], W[p + "ln_2.bias"])
+            m = gelu_new(m @ W[p + "mlp.c_fc.weight"] + W[p + "mlp.c_fc.bias"])
+            h = h + (m @ W[p + "mlp.c_proj.weight"] + W[p + "mlp.c_proj.bias"])
+        h = layer_norm(h, W["gpt.ln_f.weight"], W["gpt.ln_f.bias"])
+        return h, new_past
+
+    def head(self, h):
+        """lm_head = Sequential(final_norm, mel_head) (model_v2.py:53,185) -> fp32 logits."""
+        W = self.W
+        x = layer_norm(h, W["final_norm.weight"], W["final_norm.bias"])
+        return x @ W["mel_head.weight"].t() + W["mel_head.bias"]
+
+    # ---------------------------------------------------------- prompt (G0)
+    def prepare_gpt_inputs(self, conds_latent, text_ids, start_text=0, stop_text=1, start_mel=8192):
+        """UnifiedVoice.prepare_gpt_inputs (model_v2.py:598-661), batch 1.
+
+        conds_latent [34,D] (cond+emo, speed rows); text_ids int [L].
+        Returns fake_ids [P] int64, embeds [P-1,D], mask [P] int64.
+        """
+        W = self.W
+        text_ids = torch.as_tensor(text_ids, dtype=torch.long)
+        L = text_ids.numel()
+        valid = (text_ids != stop_text) & (text_ids != start_text)
+        t = text_ids[valid]
+        t = torch.cat((torch.tensor([start_text]), t, torch.tensor([stop_text])))
+        temb = W["text_embedding.weight"][t] + W["text_pos_embedding.emb.weight"][: t.numel()]
+        target_len = conds_latent.shape[0] + L + 2
+        mask = torch.ones(target_len + 1, dtype=torch.long)
+        pad = L + 2 - t.numel()
+        parts = [torch.as_tensor(conds_latent, dtype=torch.float32), temb]
+        if pad > 0:
+            parts.insert(0, torch.zeros(pad, self.D))
+            mask[:pad] = 0
+        embeds = torch.cat(parts, dim=0)
+        fake = torch.ones(target_len + 1, dtype=torch.long)
+        fake[-1] = start_mel
+        return fake, embeds, mask
+
+    def conds_latent(self, cond32, emo_vec):
+        """inference_speech (model_v2.py:693-696): cat(cond + emo_vec, speed_emb[1], speed_emb[0])."""
+        W = self.W
+        c = torch.as_tensor(cond32, dtype=torch.float32) + torch.as_tensor(emo_vec, dtype=torch.float32).view(1, -1)
+        return torch.cat((c, W["speed_emb.weight"][1:2], W["speed_emb.weight"][0:1]), dim=0)
+
+    # ------------------------------------------------------- prefill / decode
+    def prefill(self, embeds, mask, start_mel=8192):
+        """GPT2InferenceModel.forward, input_ids.shape[1] != 1 (model_v2.py:144-155).
+
+        embeds [P-1,D] (the stored `cached_mel_emb`), mask [P].  The start_mel_token row is
+        mel_embedding[8192] + mel_pos_embedding[0].  Returns (logits [V] of the last row, past).
+        """
+        W = self.W
+        row = W["mel_embedding.weight"][start_mel] + W["mel_pos_embedding.emb.weight"][0]
+        emb = torch.cat((embeds, row.view(1, -1)), dim=0).unsqueeze(0)
+        h, past = self.trunk(emb, None, torch.as_tensor(mask).view(1, -1))
+        return self.head(h[:, -1])[0], past
+
+    def decode_step(self, token, k, past, mask_prefix):
+        """GPT2InferenceModel.forward, input_ids.shape[1] == 1 (model_v2.py:156-160).
+
+        `token` is the k-th generated id (k >= 1); its position row is
+        mel_pos_embedding[attention_mask.shape[1] - mel_len] = [k + 1]   (SURVEY.md F6).
+        """
+        W = self.W
+        emb = (W["mel_embedding.weight"][int(token)] + W["mel_pos_embedding.emb.weight"][k + 1]).view(1, 1, -1)
+        S = past[0][0].shape[2]
+        km = torch.cat((torch.as_tensor(mask_prefix).view(1, -1), torch.ones(1, S + 1 - len(mask_prefix), dtype=torch.long)), dim=1)
+        h, past = self.trunk(emb, past, km)
+        return self.head(h[:, -1])[0], past
+
+    # -------------------------------------------------------- latent pass (G9)
+    def latent_pass(self, conds_latent, text_ids, codes, start_text=0, stop_text=1, start_mel=8192, stop_mel=8193):
+        """UnifiedVoice.forward(...)->get_logits(return_latent=True) (model_v2.py:554-596,486-512).
+
+        conds_latent [34,D]; text_ids [L]; codes [n].  Returns latent [n, D].
+        """
+        W = self.W
+        text_ids = torch.as_tensor(text_ids, dtype=torch.long)
+        codes = torch.as_tensor(codes, dtype=torch.long)
+        t = torch.cat((torch.tensor([start_text]), text_ids, torch.tensor([stop_text])))
+        temb = W["text_embedding.weight"][t] + W["text_pos_embedding.emb.weight"][: t.numel()]
+        m = torch.cat((torch.tensor([start_mel]), codes, torch.tensor([stop_mel])))
+        memb = W["mel_embedding.weight"][m] + W["mel_pos_embedding.emb.weight"][: m.numel()]
+        conds = torch.as_tensor(conds_latent, dtype=torch.float32)
+        emb = torch.cat((conds, temb, memb), dim=0).unsqueeze(0)
+        h, _ = self.trunk(emb, None, None)
+        enc = layer_norm(h[:, conds.shape[0]:], W["final_norm.weight"], W["final_norm.bias"])
+        mel = enc[0, -m.numel():]
+        return mel[:-2]
+
+
+# ------------------------------------------------------------------- sampler (G8)
+def repetition_penalty(scores, history, theta):
+    """RepetitionPenaltyLogitsProcessor: s<0 ? s*theta : s/theta on ids in history."""
+    scores = scores.clone()
+    idx = torch.unique(torch.as_tensor(history, dtype=torch.long))
+    s = scores[idx]
+    scores[idx] = torch.where(s < 0, s * theta, s / theta)
+    return scores
+
+
+def top_k_filter(scores, k, min_keep=1):
+    k = min(max(k, min_keep), scores.numel())
+    kth = torch.topk(scores, k).values[-1]
+    return scores.masked_fill(scores < kth, float("-inf"))
+
+
+def top_p_filter(scores, top_p, min_keep=1):
+    """TopPLogitsWarper: sort ascending, drop the prefix whose cumulative prob <= 1 - top_p."""
+    sorted_logits, sorted_idx = torch.sort(scores, descending=False)
+    cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+    remove_sorted = cum <= (1 - top_p)
+    remove_sorted[-min_keep:] = False
+    remove = torch.zeros_like(remove_sorted).scatter(0, sorted_idx, remove_sorted)
+    return scores.masked_fill(remove, float("-inf"))
+
+
+def process_logits(logits, history, theta=10.0, temperature=None, top_k=None, top_p=None, min_keep=1, suppress=None):
+    """Processor chain in `_get_logits_processor` order (generation_utils.py:900-901,1020-1044).
+
+    `suppress` (bench-only fixed-length mode): ids forced to -inf first.
+    """
+    s = logits.to(torch.float32).clone()
+    if suppress is not None:
+        s[torch.as_tensor(suppress, dtype=torch.long)] = float("-inf")
+    if theta is not None and theta != 1.0:
+        s = repetition_penalty(s, history, theta)
+    if temperature is not None and temperature != 1.0:
+        s = s / temperature
+    if top_k is not None and top_k > 0:
+        s = top_k_filter(s, top_k, min_keep)
+    if top_p is not None and top_p < 1.0:
+        s = top_p_filter(s, top_p, min_keep)
+    return s
+
+
+def generate_greedy(oracle, embeds, mask, max_new, theta=10.0, stop_mel=8193, start_mel=8192,
+                    suppress_stop=False, return_logits=False, forced=None):
+    """`_sample` with do_sample=False / top_k=1 (generation_utils.py:3196-3269).
+
+    History for the penalty = fake prefix [1]*(P-1)+[8192] + generated (model_v2.py:652-661, F7).
+    Returns (ids list, per-step top-2 margins[, per-step raw logits]).
+    `forced`: optional teacher-forcing ids (the argmax is still recorded in margins/logits).
+    """
+    P = len(mask)
+    history = [1] * (P - 1) + [start_mel]
+    logits, past = oracle.prefill(embeds, mask, start_mel)
+    ids, margins, all_logits = [], [], []
+    for k in range(1, max_new + 1):
+        s = process_logits(logits, history, theta, suppress=[stop_mel] if suppress_stop else None)
+        top2 = torch.topk(s, 2).values
+        margins.append(float(top2[0] - top2[1]))
+        if return_logits:
+            all_logits.append(logits.clone())
+        tok = int(torch.argmax(s))
+        if forced is not None:
+            tok = int(forced[k - 1])
+        ids.append(tok)
+        history.append(tok)
+        if tok == stop_mel or k == max_new:
+            break
+        logits, past = oracle.decode_step(tok, k, past, mask)
+    if return_logits:
+        return ids, margins, torch.stack(all_logits)
+    return ids, margins

@@ -1,0 +1,236 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own module classes (build container only).
+
+    python tests/golden/make_golden.py
+
+Imports /root/reference through tests/golden/ref_harness.py, instantiates the reference
+classes (Activation1d/SnakeBeta, BigVGAN, UnifiedVoice/GPT2InferenceModel and the
+third-party HF logits processors its generate() assembles) with seeded random weights,
+and stores inputs + reference outputs.  The .npz files are data only (no reference
+source text).  tests/test_oracle_golden.py pins oracle/ against them; the GPU tests
+compare the HIP path with both.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_harness  # noqa: E402
+
+ref_harness.install()
+
+import voice_tts_amd.weights as WR  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()})
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ----------------------------------------------------------------------------- K1 / V4
+def gen_aa_snake():
+    from indextts.s2mel.modules.bigvgan.activations import SnakeBeta
+    from indextts.s2mel.modules.bigvgan.alias_free_activation.torch.act import Activation1d
+
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    for (C, T) in [(3, 1), (3, 2), (5, 5), (4, 11), (24, 64), (6, 300), (2, 4097)]:
+        act = Activation1d(activation=SnakeBeta(C, alpha_logscale=True))
+        act.act.alpha.data = torch.randn(C, generator=g) * 0.5
+        act.act.beta.data = torch.randn(C, generator=g) * 0.5
+        x = torch.randn(2, C, T, generator=g) * 1.5
+        y = act(x)
+        tag = f"c{C}_t{T}"
+        out[f"x_{tag}"] = x
+        out[f"la_{tag}"] = act.act.alpha.data
+        out[f"lb_{tag}"] = act.act.beta.data
+        out[f"y_{tag}"] = y
+        out["up_filter"] = act.upsample.filter.flatten()
+        out["down_filter"] = act.downsample.lowpass.filter.flatten()
+    save("aa_snake.npz", **out)
+
+
+# ----------------------------------------------------------------------------- V0-V5
+def build_ref_bigvgan(cfg, W):
+    from indextts.s2mel.modules.bigvgan import bigvgan as RB
+
+    h = RB.load_hparams_from_json(os.path.join(ref_harness.REF, "indextts/s2mel/modules/bigvgan/config.json"))
+    h["upsample_initial_channel"] = cfg["upsample_initial_channel"]
+    m = RB.BigVGAN(h, use_cuda_kernel=False)
+    m.remove_weight_norm()
+    m.eval()
+    sd = m.state_dict()
+    new = {}
+    for k in sd:
+        if k in W:
+            assert tuple(sd[k].shape) == tuple(W[k].shape), k
+            new[k] = W[k]
+        else:
+            assert k.endswith("filter"), k  # registered filter buffers only
+            new[k] = sd[k]
+    missing = set(W) - set(sd)
+    assert not missing, missing
+    m.load_state_dict(new, strict=True)
+    return m
+
+
+def gen_bigvgan():
+    cfg = WR.tiny_bigvgan_cfg(64)
+    W = WR.make_bigvgan_weights(cfg, seed=21)
+    m = build_ref_bigvgan(cfg, W)
+    g = torch.Generator().manual_seed(22)
+    out = {"seed": 21, "upsample_initial_channel": 64}
+    for F in (1, 7, 40):
+        mel = (torch.randn(1, 80, F, generator=g) * 2 - 4).clamp(-11.5, 2)
+        out[f"mel_f{F}"] = mel
+        out[f"wav_f{F}"] = m(mel)
+    save("bigvgan_tiny.npz", **out)
+
+
+# ----------------------------------------------------------------------------- G0-G9
+TINY_COND = dict(output_size=32, linear_units=64, attention_heads=2, num_blocks=1, input_layer="conv2d2", perceiver_mult=2)
+
+
+def build_ref_gpt(cfg, W):
+    from indextts.gpt.model_v2 import UnifiedVoice
+
+    uv = UnifiedVoice(
+        layers=cfg["layers"], model_dim=cfg["model_dim"], heads=cfg["heads"],
+        max_text_tokens=cfg["max_text_tokens"], max_mel_tokens=cfg["max_mel_tokens"],
+        number_text_tokens=cfg["number_text_tokens"], number_mel_codes=cfg["number_mel_codes"],
+        start_mel_token=cfg["start_mel_token"], stop_mel_token=cfg["stop_mel_token"],
+        start_text_token=cfg["start_text_token"], stop_text_token=cfg["stop_text_token"],
+        mel_length_compression=1024, use_mel_codes_as_input=True, train_solo_embeddings=False,
+        condition_type="conformer_perceiver", condition_module=TINY_COND, emo_condition_module=TINY_COND,
+    ).eval()
+    sd = uv.state_dict()
+    for k, v in W.items():
+        assert k in sd and tuple(sd[k].shape) == tuple(v.shape), (k, tuple(v.shape), tuple(sd[k].shape) if k in sd else None)
+    res = uv.load_state_dict(W, strict=False)
+    assert not res.unexpected_keys
+    uv.post_init_gpt2_config(use_deepspeed=False, kv_cache=True, half=False)
+    return uv
+
+
+def ref_greedy(uv, conds_latent, text_ids, n_steps, theta=10.0, forced=None):
+    """Harness loop over the reference's own prepare_inputs_for_generation + forward."""
+    from transformers.generation.logits_process import RepetitionPenaltyLogitsProcessor
+
+    input_ids, embeds, mask = uv.prepare_gpt_inputs(conds_latent.unsqueeze(0), text_ids.unsqueeze(0))
+    model = uv.inference_model
+    model.store_mel_emb(embeds)
+    proc = RepetitionPenaltyLogitsProcessor(theta)
+    past = None
+    ids, margins, logits_all = [], [], []
+    for k in range(n_steps):
+        inp = model.prepare_inputs_for_generation(input_ids, past_key_values=past, attention_mask=mask, use_cache=True)
+        out = model(**inp, return_dict=True)
+        logits = out.logits[:, -1, :].float()
+        past = out.past_key_values
+        scores = proc(input_ids, logits.clone())
+        top2 = torch.topk(scores[0], 2).values
+        margins.append(float(top2[0] - top2[1]))
+        logits_all.append(logits[0].clone())
+        tok = int(scores[0].argmax())
+        if forced is not None:
+            tok = int(forced[k])
+        ids.append(tok)
+        input_ids = torch.cat([input_ids, torch.tensor([[tok]])], dim=1)
+        mask = torch.cat([mask, torch.ones(1, 1, dtype=mask.dtype)], dim=1)
+    return ids, margins, torch.stack(logits_all), embeds[0], mask[0, : embeds.shape[1] + 1]
+
+
+def gen_gpt():
+    cfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2)
+    W = WR.make_gpt_weights(cfg, seed=31, head_scale=50.0)
+    uv = build_ref_gpt(cfg, W)
+    g = torch.Generator().manual_seed(32)
+    D = cfg["model_dim"]
+    cond32 = torch.randn(32, D, generator=g) * 0.5
+    emo_vec = torch.randn(D, generator=g) * 0.5
+    # inference_speech:693-696
+    conds_latent = torch.cat((cond32 + emo_vec.unsqueeze(0), uv.speed_emb.weight[1:2], uv.speed_emb.weight[0:1]), 0)
+    out = dict(seed=31, model_dim=D, layers=2, heads=2, cond32=cond32, emo_vec=emo_vec, conds_latent=conds_latent)
+
+    for tag, text in (("plain", torch.randint(2, 200, (12,), generator=g)),
+                      ("padded", torch.cat((torch.tensor([0, 0, 1]), torch.randint(2, 200, (9,), generator=g))))):
+        text = text.to(torch.int32)
+        n = 40
+        ids, margins, logits, embeds, mask = ref_greedy(uv, conds_latent, text, n)
+        out[f"text_{tag}"] = text
+        out[f"embeds_{tag}"] = embeds
+        out[f"mask_{tag}"] = mask
+        out[f"ids_{tag}"] = np.array(ids)
+        out[f"margins_{tag}"] = np.array(margins)
+        out[f"logits_{tag}"] = logits[[0, 1, 2, n - 1]]
+        print(tag, "ids", ids[:12], "min margin", min(margins))
+
+    # latent pass (G9): UnifiedVoice.forward with given latent + emo_vec (model_v2.py:554-596)
+    text = out["text_plain"].long().unsqueeze(0)
+    codes = torch.tensor(out["ids_plain"][:25]).unsqueeze(0)
+    lat = uv(cond32.unsqueeze(0), text.clone(), torch.tensor([text.shape[-1]]), codes.clone(), torch.tensor([codes.shape[-1]]),
+             None, emo_vec=emo_vec.unsqueeze(0), use_speed=torch.zeros(1).long())
+    out["latent_codes"] = codes[0]
+    out["latent"] = lat[0]
+    save("gpt_tiny.npz", **out)
+
+
+def gen_gpt_block_prod():
+    """One production-width decoder layer + head: weights regenerated from the seed on both sides."""
+    cfg = dict(WR.GPT_CFG)
+    cfg.update(layers=1, max_text_tokens=40, max_mel_tokens=80, number_text_tokens=200)
+    W = WR.make_gpt_weights(cfg, seed=41, head_scale=50.0)
+    uv = build_ref_gpt(cfg, W)
+    g = torch.Generator().manual_seed(42)
+    D = cfg["model_dim"]
+    conds_latent = torch.randn(34, D, generator=g) * 0.5
+    text = torch.randint(2, 200, (6,), generator=g).to(torch.int32)
+    ids, margins, logits, embeds, mask = ref_greedy(uv, conds_latent, text, 6)
+    save("gpt_prod_layer.npz", seed=41, conds_latent=conds_latent, text=text, ids=np.array(ids), margins=np.array(margins),
+         logits_first=logits[0], logits_last=logits[-1])
+
+
+# ----------------------------------------------------------------------------- G8
+def gen_sampler():
+    from transformers.generation.logits_process import (
+        RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper)
+
+    g = torch.Generator().manual_seed(51)
+    V = 8194
+    out = {}
+    for case, min_keep in (("sample", 1), ("beam", 2)):
+        logits = torch.randn(1, V, generator=g) * 3.0
+        hist = torch.cat((torch.ones(1, 30, dtype=torch.long), torch.tensor([[8192]]), torch.randint(0, 8192, (1, 50), generator=g)), dim=1)
+        s0 = logits if case == "sample" else torch.log_softmax(logits, dim=-1)
+        s1 = RepetitionPenaltyLogitsProcessor(10.0)(hist, s0.clone())
+        s2 = TemperatureLogitsWarper(0.8)(hist, s1.clone())
+        s3 = TopKLogitsWarper(30, min_tokens_to_keep=min_keep)(hist, s2.clone())
+        s4 = TopPLogitsWarper(0.8, min_tokens_to_keep=min_keep)(hist, s3.clone())
+        out[f"{case}_in"] = s0[0]
+        out[f"{case}_hist"] = hist[0]
+        out[f"{case}_pen"] = s1[0]
+        out[f"{case}_final"] = s4[0]
+        out[f"{case}_probs"] = torch.softmax(s4[0], -1)
+    save("sampler_kat.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["aa", "bigvgan", "gpt", "prod", "sampler"]
+    if "aa" in which:
+        gen_aa_snake()
+    if "bigvgan" in which:
+        gen_bigvgan()
+    if "gpt" in which:
+        gen_gpt()
+    if "prod" in which:
+        gen_gpt_block_prod()
+    if "sampler" in which:
+        gen_sampler()

@@ -1,0 +1,134 @@
+"""Pin oracle/ (our CPU restatement) against fixtures produced by the reference's own modules.
+
+tests/golden/*.npz come from tests/golden/make_golden.py (reference classes, seeded weights).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gpt as OG
+from oracle import vocoder as OV
+import voice_tts_amd.weights as WR
+
+
+def test_filter_taps(golden):
+    g = golden("aa_snake.npz")
+    f = OV.kaiser_sinc_filter12()
+    assert np.array_equal(f, g["up_filter"])
+    assert np.array_equal(f, g["down_filter"])
+    assert abs(float(f.sum()) - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["c3_t1", "c3_t2", "c5_t5", "c4_t11", "c24_t64", "c6_t300", "c2_t4097"])
+def test_aa_snake_vs_reference(golden, tag):
+    g = golden("aa_snake.npz")
+    y = OV.aa_snake(torch.from_numpy(g[f"x_{tag}"]), g[f"la_{tag}"], g[f"lb_{tag}"])
+    ref = torch.from_numpy(g[f"y_{tag}"])
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_aa_snake_empty():
+    y = OV.aa_snake(torch.zeros(1, 3, 0), np.zeros(3, np.float32), np.zeros(3, np.float32))
+    assert y.shape == (1, 3, 0)
+
+
+@pytest.mark.parametrize("F", [1, 7, 40])
+def test_bigvgan_tiny_vs_reference(golden, F):
+    g = golden("bigvgan_tiny.npz")
+    cfg = WR.tiny_bigvgan_cfg(int(g["upsample_initial_channel"]))
+    W = WR.make_bigvgan_weights(cfg, seed=int(g["seed"]))
+    wav = OV.bigvgan_forward(torch.from_numpy(g[f"mel_f{F}"]), W, cfg)
+    ref = torch.from_numpy(g[f"wav_f{F}"])
+    assert wav.shape == ref.shape == (1, 1, 256 * F)
+    assert ref.abs().max() > 0.05  # the fixture is not degenerate
+    assert (ref.abs() >= 1.0).float().mean() < 0.2  # mostly unclamped
+    assert (wav - ref).abs().max().item() <= 2e-5
+
+
+def test_fold_weight_norm_matches_torch():
+    torch.manual_seed(0)
+    conv = torch.nn.utils.weight_norm(torch.nn.Conv1d(6, 5, 3))
+    conv.weight_g.data *= 1.0 + torch.rand_like(conv.weight_g)
+    convt = torch.nn.utils.weight_norm(torch.nn.ConvTranspose1d(6, 4, 4, 2))
+    sd = {"a." + k: v for k, v in conv.state_dict().items()}
+    sd.update({"b." + k: v for k, v in convt.state_dict().items()})
+    x = torch.randn(1, 6, 9)
+    want_a, want_b = conv(x), convt(x)
+    for fold in (WR.fold_weight_norm, OV.fold_weight_norm):
+        f = fold(sd)
+        assert set(f) == {"a.weight", "a.bias", "b.weight", "b.bias"}
+        got_a = torch.nn.functional.conv1d(x, f["a.weight"], f["a.bias"])
+        got_b = torch.nn.functional.conv_transpose1d(x, f["b.weight"], f["b.bias"], stride=2)
+        assert torch.allclose(got_a, want_a, atol=1e-6) and torch.allclose(got_b, want_b, atol=1e-6)
+    # parametrized spelling
+    conv2 = torch.nn.utils.parametrizations.weight_norm(torch.nn.Conv1d(6, 5, 3))
+    f2 = WR.fold_weight_norm({"c." + k: v for k, v in conv2.state_dict().items()})
+    assert torch.allclose(torch.nn.functional.conv1d(x, f2["c.weight"], f2["c.bias"]), conv2(x), atol=1e-6)
+
+
+def _tiny_oracle(g):
+    cfg = WR.tiny_gpt_cfg(model_dim=int(g["model_dim"]), layers=int(g["layers"]), heads=int(g["heads"]))
+    W = WR.make_gpt_weights(cfg, seed=int(g["seed"]), head_scale=50.0)
+    return OG.GptOracle(W, cfg["layers"], cfg["heads"]), cfg
+
+
+@pytest.mark.parametrize("tag", ["plain", "padded"])
+def test_gpt_prompt_and_greedy_vs_reference(golden, tag):
+    g = golden("gpt_tiny.npz")
+    orc, cfg = _tiny_oracle(g)
+    cl = orc.conds_latent(g["cond32"], g["emo_vec"])
+    assert torch.allclose(cl, torch.from_numpy(g["conds_latent"]), atol=0, rtol=0)
+    fake, embeds, mask = orc.prepare_gpt_inputs(cl, g[f"text_{tag}"])
+    assert torch.equal(mask, torch.from_numpy(g[f"mask_{tag}"]))
+    assert torch.allclose(embeds, torch.from_numpy(g[f"embeds_{tag}"]), atol=1e-7)
+    assert fake[-1] == 8192 and (fake[:-1] == 1).all()
+    if tag == "padded":
+        assert mask[:3].sum() == 0 and mask[3:].all()
+    ref_ids = g[f"ids_{tag}"].tolist()
+    n = len(ref_ids)
+    ids, margins, logits = OG.generate_greedy(orc, embeds, mask, n, return_logits=True)
+    assert ids == ref_ids
+    assert np.allclose(margins, g[f"margins_{tag}"], atol=2e-3)
+    ref_logits = torch.from_numpy(g[f"logits_{tag}"])
+    got = logits[[0, 1, 2, n - 1]]
+    assert (got - ref_logits).abs().max().item() <= 5e-4 * ref_logits.abs().max().item()
+
+
+def test_gpt_latent_pass_vs_reference(golden):
+    g = golden("gpt_tiny.npz")
+    orc, cfg = _tiny_oracle(g)
+    lat = orc.latent_pass(torch.from_numpy(g["conds_latent"]), g["text_plain"], g["latent_codes"])
+    ref = torch.from_numpy(g["latent"])
+    assert lat.shape == ref.shape == (25, cfg["model_dim"])
+    assert (lat - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_gpt_production_width_layer_vs_reference(golden):
+    g = golden("gpt_prod_layer.npz")
+    cfg = dict(WR.GPT_CFG)
+    cfg.update(layers=1, max_text_tokens=40, max_mel_tokens=80, number_text_tokens=200)
+    W = WR.make_gpt_weights(cfg, seed=int(g["seed"]), head_scale=50.0)
+    orc = OG.GptOracle(W, 1, cfg["heads"])
+    fake, embeds, mask = orc.prepare_gpt_inputs(torch.from_numpy(g["conds_latent"]), g["text"])
+    ids, margins, logits = OG.generate_greedy(orc, embeds, mask, 6, return_logits=True)
+    assert ids == g["ids"].tolist()
+    for got, ref in ((logits[0], g["logits_first"]), (logits[-1], g["logits_last"])):
+        ref = torch.from_numpy(ref)
+        assert (got - ref).abs().max().item() <= 5e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("case,min_keep", [("sample", 1), ("beam", 2)])
+def test_sampler_processors_vs_hf(golden, case, min_keep):
+    g = golden("sampler_kat.npz")
+    s_in = torch.from_numpy(g[f"{case}_in"])
+    hist = g[f"{case}_hist"].tolist()
+    pen = OG.repetition_penalty(s_in, hist, 10.0)
+    assert torch.equal(pen, torch.from_numpy(g[f"{case}_pen"]))
+    fin = OG.process_logits(s_in, hist, 10.0, 0.8, 30, 0.8, min_keep)
+    ref = torch.from_numpy(g[f"{case}_final"])
+    assert torch.equal(torch.isinf(fin), torch.isinf(ref))
+    keep = ~torch.isinf(ref)
+    assert torch.allclose(fin[keep], ref[keep], atol=1e-6)
+    assert torch.allclose(torch.softmax(fin, -1), torch.from_numpy(g[f"{case}_probs"]), atol=1e-6)
+    assert int(keep.sum()) >= min_keep
