@@ -1,0 +1,179 @@
+/* ixtts_hip.h -- C ABI of libixtts_hip.so: the MI355X (gfx950) hot path of IndexTTS2.
+ *
+ * Drop-in boundary for ONE path of caishiqing/voice-tts: the autoregressive GPT decode
+ * step and the BigVGAN vocoder of `indextts.infer_v2.IndexTTS2.infer()`.
+ * Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * Conventions
+ *   - every `*_dev` pointer is DEVICE memory on the current HIP device; `*_host` is host memory;
+ *   - `stream` is a `hipStream_t` passed as `void*` (NULL = the default stream); all
+ *     compute entry points are asynchronous on it unless stated otherwise;
+ *   - return value: 0 on success, a negative IXTTS_ERR_* code otherwise; no C++
+ *     exception crosses the ABI; `ixtts_last_error()` gives the text of the last failure
+ *     on the calling thread;
+ *   - handles are not re-entrant: one in-flight call per handle (the reference serialises
+ *     `infer()` behind `inference_lock`, server.py:25,384).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference repo root).
+ */
+#ifndef IXTTS_HIP_H
+#define IXTTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IXTTS_OK 0
+#define IXTTS_ERR_ARG (-1)   /* bad argument / shape mismatch          */
+#define IXTTS_ERR_HIP (-2)   /* a HIP runtime call failed               */
+#define IXTTS_ERR_STATE (-3) /* call order violated (e.g. not finalized) */
+#define IXTTS_ERR_NOMEM (-4) /* device/host allocation failed           */
+#define IXTTS_ERR_NAME (-5)  /* unknown tensor name                     */
+
+const char* ixtts_version(void);
+const char* ixtts_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Seam 3 -- fused anti-aliased SnakeBeta activation
+ * replaces: `extern "C" torch::Tensor fwd_cuda(input, up_filter, down_filter, alpha, beta)`
+ *   indextts/s2mel/modules/bigvgan/alias_free_activation/cuda/anti_alias_activation.cpp:19-22
+ *   indextts/s2mel/modules/bigvgan/alias_free_activation/cuda/anti_alias_activation_cuda.cu:212-246
+ * y[b,c,:] = Down2(SnakeBeta(Up2(x[b,c,:]))), 12-tap filters, replicate padding, log-scale
+ * alpha/beta [C] (exp applied inside, .cu:86-89).  Semantics follow the reference's CPU
+ * (torch) path `alias_free_activation/torch/act.py:24-30` exactly, including the sequence
+ * edges.  x, y: [B,C,T] contiguous fp32; y may not alias x.  T == 0 is a no-op.
+ */
+int ixtts_aa_snake_f32(const float* x_dev, float* y_dev, const float* up12_dev, const float* down12_dev,
+                       const float* log_alpha_dev, const float* log_beta_dev, int B, int C, int T, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Seam 2 -- BigVGAN-v2 generator
+ * replaces: `BigVGAN.__init__/remove_weight_norm/forward`
+ *   indextts/s2mel/modules/bigvgan/bigvgan.py:266-400 ; call site indextts/infer_v2.py:154-158,735
+ */
+#define IXTTS_BIGVGAN_MAX_STAGES 8
+#define IXTTS_BIGVGAN_MAX_RESK 4
+
+typedef struct ixtts_bigvgan_cfg {
+  int num_mels;                 /* 80   (config.json:44) */
+  int upsample_initial_channel; /* 1536 (config.json:13) */
+  int n_stages;                 /* 6 */
+  int upsample_rates[IXTTS_BIGVGAN_MAX_STAGES];        /* 4,4,2,2,2,2 */
+  int upsample_kernel_sizes[IXTTS_BIGVGAN_MAX_STAGES]; /* 8,8,4,4,4,4 */
+  int n_resblock_kernels;       /* 3 */
+  int resblock_kernel_sizes[IXTTS_BIGVGAN_MAX_RESK];   /* 3,7,11 */
+  int resblock_dilations[IXTTS_BIGVGAN_MAX_RESK][3];   /* 1,3,5 each */
+  int max_frames;               /* workspace is sized for mel lengths up to this */
+  int fast_sin;                 /* 0: libm-accurate sinf in the Snake (parity mode); 1: v_sin_f32 */
+} ixtts_bigvgan_cfg;
+
+typedef struct ixtts_bigvgan ixtts_bigvgan;
+
+int ixtts_bigvgan_create(ixtts_bigvgan** out, const ixtts_bigvgan_cfg* cfg);
+/* Upload one tensor of the weight-norm-FOLDED generator state dict by its reference name
+ * ("conv_pre.weight", "ups.0.0.weight", "resblocks.3.convs1.2.bias",
+ *  "resblocks.3.activations.5.act.alpha", "activation_post.act.beta", "conv_post.weight"...).
+ * `data_host` is fp32 in the reference's own layout; the library re-packs it. */
+int ixtts_bigvgan_set_tensor(ixtts_bigvgan* h, const char* name, const float* data_host, const int64_t* shape, int ndim);
+/* Verifies every tensor was supplied. */
+int ixtts_bigvgan_finalize(ixtts_bigvgan* h);
+/* Packed weight arena (device), for a one-shot RCCL broadcast at load: after
+ * `finalize` on rank 0 and `adopt_arena` elsewhere the handles are equivalent. */
+int ixtts_bigvgan_arena(ixtts_bigvgan* h, void** ptr_dev, size_t* bytes);
+int ixtts_bigvgan_adopt_arena(ixtts_bigvgan* h);
+/* mel [B,num_mels,F] fp32 -> wav [B,1,F*prod(rates)] fp32, clamp(-1,1) (bigvgan.py:360-386). */
+int ixtts_bigvgan_forward(ixtts_bigvgan* h, const float* mel_dev, int B, int F, float* wav_dev, void* stream);
+/* Algorithmic conv FLOPs of one forward at F frames. */
+double ixtts_bigvgan_flops(const ixtts_bigvgan* h, int B, int F);
+int ixtts_bigvgan_destroy(ixtts_bigvgan* h);
+
+/* ------------------------------------------------------------------------------------
+ * Seam 1 -- autoregressive GPT-2 decode engine
+ * replaces: the object DeepSpeed swaps in for `UnifiedVoice.inference_model`
+ *   indextts/gpt/model_v2.py:433-446 (seam), :45-212 (GPT2InferenceModel),
+ *   :663-734 (inference_speech -> store_mel_emb + generate), :554-596 (latent forward);
+ *   trunk arithmetic indextts/gpt/transformers_gpt2.py:480-667,985-1184;
+ *   token selection indextts/gpt/transformers_generation_utils.py:843-1070,3123-3297.
+ */
+#define IXTTS_DTYPE_F32 0
+#define IXTTS_DTYPE_BF16 1
+
+typedef struct ixtts_gpt_cfg {
+  int model_dim;       /* 1280 */
+  int layers;          /* 24   */
+  int heads;           /* 20   (head dim must be 64) */
+  int n_mel_codes;     /* 8194 (vocabulary of mel_head / mel_embedding) */
+  int n_mel_pos;       /* rows of mel_pos_embedding (max_mel_tokens + 3 = 1818) */
+  int n_text_tokens;   /* rows of text_embedding (12001) */
+  int n_text_pos;      /* rows of text_pos_embedding (602) */
+  int start_mel_token; /* 8192 */
+  int stop_mel_token;  /* 8193 */
+  int max_seq;         /* KV-cache capacity per sequence (prompt + generated) */
+  int max_batch;       /* concurrent sequences (1 greedy; beams / segment batching later) */
+  int weight_dtype;    /* IXTTS_DTYPE_F32 (parity mode) | IXTTS_DTYPE_BF16 (throughput mode) */
+} ixtts_gpt_cfg;
+
+typedef struct ixtts_sampler_cfg {
+  float repetition_penalty; /* 10.0 (infer_v2.py:605); 1.0 disables                         */
+  float temperature;        /* 0.8; ignored when do_sample == 0                              */
+  int top_k;                /* 30;  "greedy" of BASELINE configs == do_sample 0  */
+  float top_p;              /* 0.8                                                           */
+  int do_sample;            /* 0: argmax of penalised logits; 1: multinomial after warpers   */
+  int suppress_stop;        /* bench-only fixed-length mode: stop token forced to -inf       */
+  uint64_t seed;            /* Philox seed for do_sample (cannot match torch's CPU stream)   */
+} ixtts_sampler_cfg;
+
+typedef struct ixtts_gpt ixtts_gpt;
+
+int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* cfg);
+/* Upload one tensor of `UnifiedVoice.state_dict()` by name, fp32 host data in the
+ * reference layout: gpt.h.{i}.{ln_1,ln_2}.{weight,bias}, gpt.h.{i}.attn.{c_attn,c_proj}.{weight,bias},
+ * gpt.h.{i}.mlp.{c_fc,c_proj}.{weight,bias}, gpt.ln_f.*, final_norm.*, mel_head.*,
+ * mel_embedding.weight, mel_pos_embedding.emb.weight.  Other names return IXTTS_ERR_NAME. */
+int ixtts_gpt_set_tensor(ixtts_gpt* h, const char* name, const float* data_host, const int64_t* shape, int ndim);
+int ixtts_gpt_finalize(ixtts_gpt* h);
+int ixtts_gpt_arena(ixtts_gpt* h, void** ptr_dev, size_t* bytes);
+int ixtts_gpt_adopt_arena(ixtts_gpt* h);
+
+/* `store_mel_emb(embeds)` + the prefill forward of generate() for sequence slot `b`
+ * (model_v2.py:87-88,144-155): embeds_dev [P-1, D] fp32 = [pad][conds 34][text L+2] rows,
+ * attention mask = zeros for the first `n_left_pad` rows then ones (model_v2.py:635-642).
+ * Appends the start_mel_token row (mel_embedding[start] + mel_pos[0]) itself, fills the KV
+ * cache, resets the slot's history to the fake ids [1]*(P-1)+[start] (model_v2.py:652-661)
+ * and leaves the first-step logits ready. */
+int ixtts_gpt_prefill(ixtts_gpt* h, int b, const float* embeds_dev, int n_rows, int n_left_pad, void* stream);
+/* Run up to `n_steps` decode steps for slots [0, n_active): logits -> processors -> token ->
+ * embed -> 24 layers.  No host synchronisation inside; a slot that emits stop_mel_token
+ * keeps emitting it (generation_utils.py:3255-3256).  Tokens accumulate on the device. */
+int ixtts_gpt_decode(ixtts_gpt* h, int n_active, int n_steps, const ixtts_sampler_cfg* sc, void* stream);
+/* Synchronises `stream`; returns generated ids of slot b (up to and including the first
+ * stop token) and whether the slot has finished. */
+int ixtts_gpt_read(ixtts_gpt* h, int b, int32_t* ids_host, int cap, int* n_ids, int* finished, void* stream);
+/* Raw fp32 logits of the most recent forward for slot b ([n_mel_codes], device -> host, sync). */
+int ixtts_gpt_read_logits(ixtts_gpt* h, int b, float* logits_host, void* stream);
+/* Teacher forcing for parity tests: overrides the NEXT token chosen for slot b. */
+int ixtts_gpt_force_next(ixtts_gpt* h, int b, int32_t token, void* stream);
+
+/* `UnifiedVoice.forward(...)->get_logits(return_latent=True)` (model_v2.py:554-596,486-512):
+ * prefix_dev [n_prefix, D] = [conds 34 ; text_emb L+2] rows; codes_dev [n] int32 mel codes.
+ * Embeds [start, codes, stop] with mel positions 0..n+1, runs the full causal trunk,
+ * ln_f + final_norm, writes the first n mel rows to latent_dev [n, D] fp32. */
+int ixtts_gpt_latent(ixtts_gpt* h, const float* prefix_dev, int n_prefix, const int32_t* codes_dev, int n,
+                     float* latent_dev, void* stream);
+
+/* Microbench hook for bench.py's roofline leg: launches the decode-step GEMV kernel of
+ * `which` (0 qkv, 1 attn-out, 2 fc, 3 mlp-out, 4 head) for layer `layer` once on `stream`. */
+int ixtts_gpt_bench_gemv(ixtts_gpt* h, int which, int layer, int batch, void* stream);
+/* Algorithmic HBM bytes of one decode step at batch B and context S. */
+double ixtts_gpt_step_bytes(const ixtts_gpt* h, int B, int S);
+
+int ixtts_gpt_destroy(ixtts_gpt* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IXTTS_HIP_H */

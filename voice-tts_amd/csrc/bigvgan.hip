@@ -1,0 +1,388 @@
+// bigvgan.hip -- BigVGAN-v2 generator forward on gfx950: host orchestration + C ABI (seam 2).
+//
+// Reference: indextts/s2mel/modules/bigvgan/bigvgan.py:243-400 (BigVGAN), :31-147 (AMPBlock1);
+// call site indextts/infer_v2.py:154-158,735.
+//
+// HBM layout
+//   weight arena (one hipMalloc, broadcastable): per conv  Wp[phase][tap][Cin_pad][Cout_pad] fp32
+//   + bias[Cout]; per activation log_alpha[C], log_beta[C]; the 12 filter taps.
+//   activations: 5 ping-pong buffers of 6144*F*B floats ([B][C][T] row-major, T contiguous):
+//     XS  previous stage output / 3-way resblock accumulator      X   stage input (after ups)
+//     R   running resblock state   T1  activation output   T2  conv1 output
+#include <map>
+#include <vector>
+
+#include "conv.h"
+
+namespace ixtts {
+
+struct ConvDesc {
+  size_t w_off = 0, b_off = 0;  // float offsets into the arena
+  int Cin = 0, Cout = 0, Cin_pad = 0, Cout_pad = 0, K = 0, dil = 1, pad = 0;
+  int stride = 1;  // >1: transposed conv
+  bool has_bias = true;
+  bool w_set = false, b_set = false;
+};
+
+struct ActDesc {
+  size_t a_off = 0, b_off = 0;
+  int C = 0;
+  bool a_set = false, b_set = false;
+};
+
+}  // namespace ixtts
+
+using namespace ixtts;
+
+struct ixtts_bigvgan {
+  ixtts_bigvgan_cfg cfg;
+  std::map<std::string, ConvDesc> convs;
+  std::map<std::string, ActDesc> acts;
+  float* arena = nullptr;
+  size_t arena_floats = 0;
+  size_t filt_off = 0;
+  float* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t buf_floats = 0;
+  int total_up = 1;
+  bool finalized = false;
+};
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+static void add_conv(ixtts_bigvgan* h, const std::string& name, int Cin, int Cout, int K, int dil, int stride, bool bias,
+                     size_t& off) {
+  ConvDesc d;
+  d.Cin = Cin;
+  d.Cout = Cout;
+  d.K = K;
+  d.dil = dil;
+  d.stride = stride;
+  d.has_bias = bias;
+  d.Cin_pad = round_up(Cin, 8);
+  d.Cout_pad = round_up(Cout, conv_tile_bm(Cout));
+  d.pad = stride == 1 ? (K * dil - dil) / 2 : (K - stride) / 2;
+  d.w_off = off;
+  off += (size_t)K * d.Cin_pad * d.Cout_pad;  // K taps in total (phases * taps-per-phase for transposed)
+  off = (off + 3) & ~(size_t)3;
+  d.b_off = off;
+  off += round_up(Cout, 4);
+  h->convs[name] = d;
+}
+
+static void add_act(ixtts_bigvgan* h, const std::string& name, int C, size_t& off) {
+  ActDesc a;
+  a.C = C;
+  a.a_off = off;
+  off += round_up(C, 4);
+  a.b_off = off;
+  off += round_up(C, 4);
+  h->acts[name] = a;
+}
+
+extern "C" int ixtts_bigvgan_create(ixtts_bigvgan** out, const ixtts_bigvgan_cfg* cfg) {
+  IX_ARG(out && cfg, "bigvgan_create: null argument");
+  IX_ARG(cfg->n_stages >= 1 && cfg->n_stages <= IXTTS_BIGVGAN_MAX_STAGES, "bigvgan_create: n_stages %d", cfg->n_stages);
+  IX_ARG(cfg->n_resblock_kernels >= 1 && cfg->n_resblock_kernels <= IXTTS_BIGVGAN_MAX_RESK, "bigvgan_create: n_resblock_kernels");
+  IX_ARG(cfg->n_resblock_kernels == 3, "bigvgan_create: the fused /3 epilogue assumes 3 resblocks per stage");
+  IX_ARG(cfg->num_mels > 0 && cfg->upsample_initial_channel > 0 && cfg->max_frames > 0, "bigvgan_create: bad sizes");
+  IX_ARG((cfg->upsample_initial_channel >> cfg->n_stages) >= 1, "bigvgan_create: channels vanish");
+  auto* h = new (std::nothrow) ixtts_bigvgan();
+  if (!h) return IXTTS_ERR_NOMEM;
+  h->cfg = *cfg;
+  size_t off = 0;
+  h->filt_off = off;
+  off += 16;
+  int c = cfg->upsample_initial_channel;
+  add_conv(h, "conv_pre", cfg->num_mels, c, 7, 1, 1, true, off);
+  size_t max_ct = (size_t)c;  // C*T per frame
+  int up = 1;
+  for (int i = 0; i < cfg->n_stages; ++i) {
+    int u = cfg->upsample_rates[i], ku = cfg->upsample_kernel_sizes[i];
+    if (u < 1 || ku % u != 0 || (ku - u) % 2 != 0) {
+      delete h;
+      set_error("bigvgan_create: stage %d: kernel %d must be a multiple of stride %d with even k-s", i, ku, u);
+      return IXTTS_ERR_ARG;
+    }
+    add_conv(h, "ups." + std::to_string(i) + ".0", c, c / 2, ku, 1, u, true, off);
+    c /= 2;
+    up *= u;
+    if ((size_t)c * up > max_ct) max_ct = (size_t)c * up;
+    for (int j = 0; j < cfg->n_resblock_kernels; ++j) {
+      std::string p = "resblocks." + std::to_string(i * cfg->n_resblock_kernels + j);
+      int k = cfg->resblock_kernel_sizes[j];
+      for (int m = 0; m < 3; ++m) {
+        add_conv(h, p + ".convs1." + std::to_string(m), c, c, k, cfg->resblock_dilations[j][m], 1, true, off);
+        add_conv(h, p + ".convs2." + std::to_string(m), c, c, k, 1, 1, true, off);
+      }
+      for (int m = 0; m < 6; ++m) add_act(h, p + ".activations." + std::to_string(m) + ".act", c, off);
+    }
+  }
+  add_act(h, "activation_post.act", c, off);
+  // conv_post is Cout=1: stored unpacked [C][7]
+  {
+    ConvDesc d;
+    d.Cin = c;
+    d.Cout = 1;
+    d.K = 7;
+    d.has_bias = false;
+    d.b_set = true;
+    d.w_off = off;
+    off += round_up(c * 7, 4);
+    d.b_off = off;
+    off += 4;
+    h->convs["conv_post"] = d;
+  }
+  h->total_up = up;
+  h->arena_floats = off;
+  if (hipMalloc(&h->arena, off * sizeof(float)) != hipSuccess) {
+    delete h;
+    set_error("bigvgan_create: hipMalloc(%zu) failed", off * sizeof(float));
+    return IXTTS_ERR_NOMEM;
+  }
+  hipMemset(h->arena, 0, off * sizeof(float));
+  *out = h;
+  return IXTTS_OK;
+}
+
+static int ensure_workspace(ixtts_bigvgan* h, int B, int F) {
+  size_t per_frame = 0;
+  int c = h->cfg.upsample_initial_channel, up = 1;
+  per_frame = (size_t)c;
+  for (int i = 0; i < h->cfg.n_stages; ++i) {
+    c /= 2;
+    up *= h->cfg.upsample_rates[i];
+    if ((size_t)c * up > per_frame) per_frame = (size_t)c * up;
+  }
+  size_t need = per_frame * (size_t)F * B;
+  if (need <= h->buf_floats) return IXTTS_OK;
+  for (int i = 0; i < 5; ++i) {
+    if (h->buf[i]) hipFree(h->buf[i]);
+    h->buf[i] = nullptr;
+  }
+  h->buf_floats = 0;
+  for (int i = 0; i < 5; ++i) {
+    if (hipMalloc(&h->buf[i], need * sizeof(float)) != hipSuccess) {
+      set_error("bigvgan: workspace hipMalloc(%zu) failed", need * sizeof(float));
+      return IXTTS_ERR_NOMEM;
+    }
+  }
+  h->buf_floats = need;
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_bigvgan_set_tensor(ixtts_bigvgan* h, const char* name, const float* data, const int64_t* shape,
+                                        int ndim) {
+  IX_ARG(h && name && data && shape, "bigvgan_set_tensor: null argument");
+  std::string n(name);
+  auto ends = [&](const char* s) { size_t L = strlen(s); return n.size() >= L && n.compare(n.size() - L, L, s) == 0; };
+  if (ends(".alpha") || ends(".beta")) {
+    bool is_a = ends(".alpha");
+    std::string base = n.substr(0, n.rfind('.'));
+    auto it = h->acts.find(base);
+    if (it == h->acts.end()) { set_error("bigvgan_set_tensor: unknown tensor '%s'", name); return IXTTS_ERR_NAME; }
+    ActDesc& a = it->second;
+    IX_ARG(ndim == 1 && shape[0] == a.C, "bigvgan_set_tensor: %s expects [%d]", name, a.C);
+    IX_HIP(hipMemcpy(h->arena + (is_a ? a.a_off : a.b_off), data, a.C * sizeof(float), hipMemcpyHostToDevice));
+    (is_a ? a.a_set : a.b_set) = true;
+    return IXTTS_OK;
+  }
+  bool is_w = ends(".weight"), is_b = ends(".bias");
+  if (!is_w && !is_b) { set_error("bigvgan_set_tensor: unknown tensor '%s'", name); return IXTTS_ERR_NAME; }
+  std::string base = n.substr(0, n.rfind('.'));
+  auto it = h->convs.find(base);
+  if (it == h->convs.end()) { set_error("bigvgan_set_tensor: unknown tensor '%s'", name); return IXTTS_ERR_NAME; }
+  ConvDesc& d = it->second;
+  if (is_b) {
+    IX_ARG(d.has_bias, "bigvgan_set_tensor: %s has no bias in this configuration", base.c_str());
+    IX_ARG(ndim == 1 && shape[0] == d.Cout, "bigvgan_set_tensor: %s expects [%d]", name, d.Cout);
+    IX_HIP(hipMemcpy(h->arena + d.b_off, data, d.Cout * sizeof(float), hipMemcpyHostToDevice));
+    d.b_set = true;
+    return IXTTS_OK;
+  }
+  IX_ARG(ndim == 3, "bigvgan_set_tensor: %s expects 3 dims", name);
+  if (base == "conv_post") {
+    IX_ARG(shape[0] == 1 && shape[1] == d.Cin && shape[2] == 7, "bigvgan_set_tensor: conv_post.weight expects [1,%d,7]", d.Cin);
+    IX_HIP(hipMemcpy(h->arena + d.w_off, data, d.Cin * 7 * sizeof(float), hipMemcpyHostToDevice));
+    d.w_set = true;
+    return IXTTS_OK;
+  }
+  std::vector<float> packed((size_t)d.K * d.Cin_pad * d.Cout_pad, 0.f);
+  if (d.stride == 1) {
+    // Conv1d weight [Cout][Cin][K] -> Wp[k][ci][co]
+    IX_ARG(shape[0] == d.Cout && shape[1] == d.Cin && shape[2] == d.K, "bigvgan_set_tensor: %s expects [%d,%d,%d]", name, d.Cout, d.Cin, d.K);
+    for (int co = 0; co < d.Cout; ++co)
+      for (int ci = 0; ci < d.Cin; ++ci)
+        for (int k = 0; k < d.K; ++k)
+          packed[((size_t)k * d.Cin_pad + ci) * d.Cout_pad + co] = data[((size_t)co * d.Cin + ci) * d.K + k];
+  } else {
+    // ConvTranspose1d weight [Cin][Cout][K] -> Wp[phase r][j][ci][co], k = r + stride*j
+    IX_ARG(shape[0] == d.Cin && shape[1] == d.Cout && shape[2] == d.K, "bigvgan_set_tensor: %s expects [%d,%d,%d]", name, d.Cin, d.Cout, d.K);
+    int J = d.K / d.stride;
+    for (int ci = 0; ci < d.Cin; ++ci)
+      for (int co = 0; co < d.Cout; ++co)
+        for (int k = 0; k < d.K; ++k) {
+          int r = k % d.stride, j = k / d.stride;
+          packed[(((size_t)r * J + j) * d.Cin_pad + ci) * d.Cout_pad + co] = data[((size_t)ci * d.Cout + co) * d.K + k];
+        }
+  }
+  IX_HIP(hipMemcpy(h->arena + d.w_off, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+  d.w_set = true;
+  return IXTTS_OK;
+}
+
+// 12-tap Kaiser-sinc (filter.py:30-62 with cutoff .25, half-width .3): computed in double,
+// rounded to fp32.  The Python binding overwrites these with torch's fp32 taps via the
+// pseudo-tensor "filter" so both sides use bit-identical coefficients.
+static void default_filter(float* f) {
+  const double taps[12] = {0.0020289646927267313, 0.009389465674757957, -0.0255434587597847, -0.057657383382320404,
+                           0.12857258319854736,   0.44320979714393616,  0.44320979714393616,  0.12857258319854736,
+                           -0.057657383382320404, -0.0255434587597847,  0.009389465674757957, 0.0020289646927267313};
+  for (int i = 0; i < 12; ++i) f[i] = (float)taps[i];
+}
+
+extern "C" int ixtts_bigvgan_finalize(ixtts_bigvgan* h) {
+  IX_ARG(h, "bigvgan_finalize: null handle");
+  for (auto& kv : h->convs) {
+    if (!kv.second.w_set || (kv.second.has_bias && !kv.second.b_set)) {
+      set_error("bigvgan_finalize: tensor(s) of '%s' were not supplied", kv.first.c_str());
+      return IXTTS_ERR_STATE;
+    }
+  }
+  for (auto& kv : h->acts) {
+    if (!kv.second.a_set || !kv.second.b_set) {
+      set_error("bigvgan_finalize: alpha/beta of '%s' were not supplied", kv.first.c_str());
+      return IXTTS_ERR_STATE;
+    }
+  }
+  float f[16] = {0};
+  default_filter(f);
+  IX_HIP(hipMemcpy(h->arena + h->filt_off, f, sizeof(f), hipMemcpyHostToDevice));
+  IX_TRY(ensure_workspace(h, 1, h->cfg.max_frames));
+  h->finalized = true;
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_bigvgan_arena(ixtts_bigvgan* h, void** ptr, size_t* bytes) {
+  IX_ARG(h && ptr && bytes, "bigvgan_arena: null argument");
+  *ptr = h->arena;
+  *bytes = h->arena_floats * sizeof(float);
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_bigvgan_adopt_arena(ixtts_bigvgan* h) {
+  IX_ARG(h, "bigvgan_adopt_arena: null handle");
+  IX_TRY(ensure_workspace(h, 1, h->cfg.max_frames));
+  h->finalized = true;
+  return IXTTS_OK;
+}
+
+static int run_act(ixtts_bigvgan* h, const std::string& name, const float* x, float* y, int B, int T, hipStream_t st) {
+  const ActDesc& a = h->acts.at(name);
+  const float* f = h->arena + h->filt_off;
+  return launch_aa_snake(x, y, f, f, h->arena + a.a_off, h->arena + a.b_off, B, a.C, T, h->cfg.fast_sin != 0, st);
+}
+
+static int run_conv(ixtts_bigvgan* h, const std::string& name, const float* x, float* y, const float* res,
+                    const float* accum, int div3, int B, int Tin, hipStream_t st) {
+  const ConvDesc& d = h->convs.at(name);
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.wp = h->arena + d.w_off;
+  p.bias = d.has_bias ? h->arena + d.b_off : nullptr;
+  p.res = res;
+  p.accum = accum;
+  p.y = y;
+  p.B = B;
+  p.Cin = d.Cin;
+  p.Cin_pad = d.Cin_pad;
+  p.Cout = d.Cout;
+  p.Cout_pad = d.Cout_pad;
+  p.Tin = Tin;
+  p.div3 = div3;
+  if (d.stride == 1) {
+    p.Tout = Tin;
+    p.ntap = d.K;
+    p.dil = d.dil;
+    p.off0 = -d.pad;
+    p.os = 1;
+    p.oo = 0;
+    p.Nq = Tin;
+    p.nphase = 1;
+  } else {
+    // phase r: t = q*s + r - pad, input index q - j (j = 0..K/s-1)  => dil = -1, off0 = 0
+    p.Tout = Tin * d.stride;
+    p.ntap = d.K / d.stride;
+    p.dil = -1;
+    p.off0 = 0;
+    p.os = d.stride;
+    p.oo = -d.pad;
+    p.Nq = Tin + p.ntap;  // q up to Tin-1+ (ntap-1) still touches valid inputs; extra column is masked
+    p.nphase = d.stride;
+  }
+  return launch_conv1d(p, st);
+}
+
+extern "C" int ixtts_bigvgan_forward(ixtts_bigvgan* h, const float* mel, int B, int F, float* wav, void* stream) {
+  IX_ARG(h && (mel || F == 0) && (wav || F == 0), "bigvgan_forward: null argument");
+  if (!h->finalized) { set_error("bigvgan_forward: handle not finalized"); return IXTTS_ERR_STATE; }
+  IX_ARG(B >= 0 && F >= 0, "bigvgan_forward: negative shape");
+  if (B == 0 || F == 0) return IXTTS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  IX_TRY(ensure_workspace(h, B, F));
+  float *XS = h->buf[0], *X = h->buf[1], *R = h->buf[2], *T1 = h->buf[3], *T2 = h->buf[4];
+  const ixtts_bigvgan_cfg& c = h->cfg;
+  IX_TRY(run_conv(h, "conv_pre", mel, XS, nullptr, nullptr, 0, B, F, st));
+  int T = F;
+  for (int i = 0; i < c.n_stages; ++i) {
+    IX_TRY(run_conv(h, "ups." + std::to_string(i) + ".0", XS, X, nullptr, nullptr, 0, B, T, st));
+    T *= c.upsample_rates[i];
+    for (int j = 0; j < c.n_resblock_kernels; ++j) {
+      std::string p = "resblocks." + std::to_string(i * c.n_resblock_kernels + j);
+      const float* cur = X;
+      for (int m = 0; m < 3; ++m) {
+        IX_TRY(run_act(h, p + ".activations." + std::to_string(2 * m) + ".act", cur, T1, B, T, st));
+        IX_TRY(run_conv(h, p + ".convs1." + std::to_string(m), T1, T2, nullptr, nullptr, 0, B, T, st));
+        IX_TRY(run_act(h, p + ".activations." + std::to_string(2 * m + 1) + ".act", T2, T1, B, T, st));
+        if (m < 2) {
+          IX_TRY(run_conv(h, p + ".convs2." + std::to_string(m), T1, R, cur, nullptr, 0, B, T, st));
+          cur = R;
+        } else {
+          // xs = r0 ; xs += r1 ; x = (xs + r2) / 3      (bigvgan.py:369-375)
+          const float* accum = (j == 0) ? nullptr : XS;
+          int div3 = (j == c.n_resblock_kernels - 1) ? 1 : 0;
+          IX_TRY(run_conv(h, p + ".convs2." + std::to_string(m), T1, XS, cur, accum, div3, B, T, st));
+        }
+      }
+    }
+  }
+  IX_TRY(run_act(h, "activation_post.act", XS, T1, B, T, st));
+  const ConvDesc& cp = h->convs.at("conv_post");
+  IX_TRY(launch_conv_post(T1, h->arena + cp.w_off, nullptr, wav, B, cp.Cin, T, st));
+  return IXTTS_OK;
+}
+
+extern "C" double ixtts_bigvgan_flops(const ixtts_bigvgan* h, int B, int F) {
+  if (!h) return 0.0;
+  const ixtts_bigvgan_cfg& c = h->cfg;
+  double fl = 2.0 * c.num_mels * c.upsample_initial_channel * 7 * F;
+  double T = F;
+  int ch = c.upsample_initial_channel;
+  for (int i = 0; i < c.n_stages; ++i) {
+    fl += 2.0 * ch * (ch / 2) * c.upsample_kernel_sizes[i] * T;
+    T *= c.upsample_rates[i];
+    ch /= 2;
+    for (int j = 0; j < c.n_resblock_kernels; ++j) fl += 6.0 * 2.0 * ch * ch * c.resblock_kernel_sizes[j] * T;
+  }
+  fl += 2.0 * ch * 7 * T;
+  return fl * B;
+}
+
+extern "C" int ixtts_bigvgan_destroy(ixtts_bigvgan* h) {
+  if (!h) return IXTTS_OK;
+  if (h->arena) hipFree(h->arena);
+  for (int i = 0; i < 5; ++i)
+    if (h->buf[i]) hipFree(h->buf[i]);
+  delete h;
+  return IXTTS_OK;
+}
