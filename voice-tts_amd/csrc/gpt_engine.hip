@@ -1,21 +1,670 @@
-// gpt_engine.hip -- placeholder until the decode engine lands (every call reports IXTTS_ERR_STATE).
-#include "common.h"
+// gpt_engine.hip -- autoregressive GPT-2 decode engine on gfx950: host side + C ABI (seam 1).
+//
+// Replaces the object DeepSpeed swaps in for `UnifiedVoice.inference_model`
+// (indextts/gpt/model_v2.py:433-446).  Reference behaviour restated:
+//   prefill / decode embed   model_v2.py:144-160 (F6: k-th generated token sits at mel-pos k+1)
+//   trunk                    transformers_gpt2.py:480-667,985-1184 (wpe == 0, model_v2.py:22-23,274)
+//   head                     model_v2.py:53,185 (final_norm after ln_f, then mel_head)
+//   token selection          transformers_generation_utils.py:3196-3269 + RepetitionPenalty
+//   latent pass              model_v2.py:554-596,486-512
+//
+// HBM layout (one arena, broadcastable with one RCCL call):
+//   per layer: ln_1 w,b | Wqkv^T [3D][D] | b | Wo^T [D][D] | b | ln_2 w,b | Wfc^T [4D][D] | b | Wpr^T [D][4D] | b
+//   ln_f, final_norm, Whead [V][D], b, mel_embedding [V][D] fp32, mel_pos_embedding [n_pos][D] fp32.
+//   Matrices are stored TRANSPOSED (output row contiguous over K) in fp32 or bf16 so one
+//   wavefront streams whole rows with 16-byte-per-lane loads; vectors stay fp32.
+//   KV cache: [layer][slot][head][max_seq][64] (fp32 in parity mode, bf16 in throughput mode).
+#include <map>
+#include <vector>
+
+#include "gpt_kernels.h"
+
 using namespace ixtts;
-struct ixtts_gpt { int dummy; };
-#define NOTYET(name) do { set_error(name ": decode engine not built yet"); return IXTTS_ERR_STATE; } while (0)
-extern "C" {
-int ixtts_gpt_create(ixtts_gpt**, const ixtts_gpt_cfg*) { NOTYET("gpt_create"); }
-int ixtts_gpt_set_tensor(ixtts_gpt*, const char*, const float*, const int64_t*, int) { NOTYET("gpt_set_tensor"); }
-int ixtts_gpt_finalize(ixtts_gpt*) { NOTYET("gpt_finalize"); }
-int ixtts_gpt_arena(ixtts_gpt*, void**, size_t*) { NOTYET("gpt_arena"); }
-int ixtts_gpt_adopt_arena(ixtts_gpt*) { NOTYET("gpt_adopt_arena"); }
-int ixtts_gpt_prefill(ixtts_gpt*, int, const float*, int, int, void*) { NOTYET("gpt_prefill"); }
-int ixtts_gpt_decode(ixtts_gpt*, int, int, const ixtts_sampler_cfg*, void*) { NOTYET("gpt_decode"); }
-int ixtts_gpt_read(ixtts_gpt*, int, int32_t*, int, int*, int*, void*) { NOTYET("gpt_read"); }
-int ixtts_gpt_read_logits(ixtts_gpt*, int, float*, void*) { NOTYET("gpt_read_logits"); }
-int ixtts_gpt_force_next(ixtts_gpt*, int, int32_t, void*) { NOTYET("gpt_force_next"); }
-int ixtts_gpt_latent(ixtts_gpt*, const float*, int, const int32_t*, int, float*, void*) { NOTYET("gpt_latent"); }
-int ixtts_gpt_bench_gemv(ixtts_gpt*, int, int, int, void*) { NOTYET("gpt_bench_gemv"); }
-double ixtts_gpt_step_bytes(const ixtts_gpt*, int, int) { return 0.0; }
-int ixtts_gpt_destroy(ixtts_gpt*) { return IXTTS_OK; }
+
+namespace {
+
+constexpr int MAXB = 4;
+
+enum TKind { T_VEC = 0, T_MAT_T = 1, T_MAT_N = 2, T_EMB = 3 };
+
+struct TDesc {
+  size_t off = 0;  // byte offset in the arena
+  int kind = T_VEC;
+  int64_t d0 = 0, d1 = 0;  // expected shape ([d0] or [d0][d1] as in the state dict)
+  bool set = false;
+};
+
+struct LayerOff {
+  size_t ln1_w, ln1_b, wqkv, bqkv, wo, bo, ln2_w, ln2_b, wfc, bfc, wpr, bpr;
+};
+
+template <int D>
+struct Dims;
+template <>
+struct Dims<1280> {
+  static constexpr int R1 = 2, R4 = 1, U_QKV = 2, U_OUT = 1, U_FC = 2, U_PR = 1, U_HEAD = 4;
+};
+template <>
+struct Dims<128> {
+  static constexpr int R1 = 4, R4 = 1, U_QKV = 1, U_OUT = 1, U_FC = 1, U_PR = 1, U_HEAD = 1;
+};
+
+}  // namespace
+
+struct ixtts_gpt {
+  ixtts_gpt_cfg cfg;
+  int D, L, H, V, FF, slots, smax;
+  size_t esize;
+  uint8_t* arena = nullptr;
+  size_t arena_bytes = 0;
+  std::vector<LayerOff> lo;
+  size_t lnf_w, lnf_b, fn_w, fn_b, whead, bhead, mel_emb, mel_pos;
+  std::map<std::string, TDesc> tens;
+  bool finalized = false;
+  // state
+  float *h = nullptr, *q = nullptr, *ff = nullptr, *part = nullptr, *logits = nullptr, *rowbuf = nullptr;
+  void *kc = nullptr, *vc = nullptr;
+  int *cur_len = nullptr, *gen_count = nullptr, *prompt_len = nullptr, *valid_from = nullptr, *finished = nullptr,
+      *forced = nullptr;
+  int32_t* tokens = nullptr;
+  uint8_t* seen = nullptr;
+  ixtts_sampler_cfg* d_samp = nullptr;
+  ixtts_sampler_cfg samp_host;
+  float* scratch = nullptr;
+  size_t scratch_floats = 0;
+  hipStream_t cap_stream = nullptr;
+  hipGraphExec_t step_exec[MAXB + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int nsplit[MAXB + 1];
+  int host_prompt_len[MAXB + 2];
+  int host_gen_est[MAXB + 2];
+};
+
+#define A_F32(off) reinterpret_cast<float*>(h->arena + (off))
+#define A_PTR(off) reinterpret_cast<void*>(h->arena + (off))
+
+// ------------------------------------------------------------------------------------ launch helpers
+template <typename WT, typename KVT, int K, int ROWS, int UNITS, int B, int INP, int EPI>
+static int launch_gemv(const GemvArgs& a, hipStream_t st) {
+  auto kern = gemv_kernel<WT, K, ROWS, UNITS, B, INP, EPI, KVT>;
+  const size_t smem = (size_t)B * K * sizeof(float);
+  if (smem > 64 * 1024) {
+    static bool done = false;
+    if (!done) {
+      IX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      done = true;
+    }
+  }
+  const int n_units = (a.N + ROWS - 1) / ROWS;
+  const int grid = ceil_div(n_units, 4 * UNITS);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, a);
+  return IXTTS_OK;
+}
+
+template <typename WT, typename KVT, int D, int B>
+static int gemv_qkv(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
+  using DM = Dims<D>;
+  const LayerOff& o = h->lo[l];
+  GemvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.wt = A_PTR(o.wqkv);
+  a.bias = A_F32(o.bqkv);
+  a.N = 3 * D;
+  a.slot0 = slot0;
+  a.xin = h->h;
+  a.ln_w = A_F32(o.ln1_w);
+  a.ln_b = A_F32(o.ln1_b);
+  a.out = h->q;
+  a.out_stride = D;
+  const size_t lstride = (size_t)h->slots * D * h->smax * sizeof(KVT);
+  a.kcache = (uint8_t*)h->kc + l * lstride;
+  a.vcache = (uint8_t*)h->vc + l * lstride;
+  a.cur_len = h->cur_len;
+  a.smax = h->smax;
+  a.heads = h->H;
+  return launch_gemv<WT, KVT, D, DM::R1, DM::U_QKV, B, IN_LN, EPI_QKV>(a, st);
+}
+
+template <typename WT, typename KVT, int D, int B>
+static int gemv_out(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
+  using DM = Dims<D>;
+  const LayerOff& o = h->lo[l];
+  GemvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.wt = A_PTR(o.wo);
+  a.bias = A_F32(o.bo);
+  a.N = D;
+  a.slot0 = slot0;
+  a.xin = h->part;
+  a.nsplit = h->nsplit[B];
+  a.out = h->h;
+  a.out_stride = D;
+  return launch_gemv<WT, KVT, D, DM::R1, DM::U_OUT, B, IN_ATTN, EPI_RESID>(a, st);
+}
+
+template <typename WT, typename KVT, int D, int B>
+static int gemv_fc(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
+  using DM = Dims<D>;
+  const LayerOff& o = h->lo[l];
+  GemvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.wt = A_PTR(o.wfc);
+  a.bias = A_F32(o.bfc);
+  a.N = 4 * D;
+  a.slot0 = slot0;
+  a.xin = h->h;
+  a.ln_w = A_F32(o.ln2_w);
+  a.ln_b = A_F32(o.ln2_b);
+  a.out = h->ff;
+  a.out_stride = 4 * D;
+  return launch_gemv<WT, KVT, D, DM::R1, DM::U_FC, B, IN_LN, EPI_GELU>(a, st);
+}
+
+template <typename WT, typename KVT, int D, int B>
+static int gemv_pr(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
+  using DM = Dims<D>;
+  const LayerOff& o = h->lo[l];
+  GemvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.wt = A_PTR(o.wpr);
+  a.bias = A_F32(o.bpr);
+  a.N = D;
+  a.slot0 = slot0;
+  a.xin = h->ff;
+  a.out = h->h;
+  a.out_stride = D;
+  return launch_gemv<WT, KVT, 4 * D, DM::R4, DM::U_PR, B, IN_PLAIN, EPI_RESID>(a, st);
+}
+
+template <typename WT, typename KVT, int D, int B>
+static int gemv_head(ixtts_gpt* h, int slot0, float* norm_out, hipStream_t st) {
+  using DM = Dims<D>;
+  GemvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.wt = A_PTR(h->whead);
+  a.bias = A_F32(h->bhead);
+  a.N = h->V;
+  a.slot0 = slot0;
+  a.xin = h->h;
+  a.ln_w = A_F32(h->lnf_w);
+  a.ln_b = A_F32(h->lnf_b);
+  a.ln2_w = A_F32(h->fn_w);
+  a.ln2_b = A_F32(h->fn_b);
+  a.out = h->logits;
+  a.out_stride = h->V;
+  a.norm_out = norm_out;
+  return launch_gemv<WT, KVT, D, DM::R1, DM::U_HEAD, B, IN_LN2, EPI_LOGITS>(a, st);
+}
+
+template <typename WT, typename KVT, int D, int B>
+static int forward_layers(ixtts_gpt* h, int slot0, hipStream_t st) {
+  const size_t lstride = (size_t)h->slots * D * h->smax * sizeof(KVT);
+  for (int l = 0; l < h->L; ++l) {
+    IX_TRY((gemv_qkv<WT, KVT, D, B>(h, l, slot0, st)));
+    AttnArgs t;
+    t.q = h->q;
+    t.kcache = (uint8_t*)h->kc + l * lstride;
+    t.vcache = (uint8_t*)h->vc + l * lstride;
+    t.part = h->part;
+    t.cur_len = h->cur_len;
+    t.valid_from = h->valid_from;
+    t.slot0 = slot0;
+    t.heads = h->H;
+    t.smax = h->smax;
+    t.nsplit = h->nsplit[B];
+    t.D = D;
+    hipLaunchKernelGGL(attn_decode_kernel<KVT>, dim3(h->H, h->nsplit[B], B), dim3(256), 0, st, t);
+    IX_TRY((gemv_out<WT, KVT, D, B>(h, l, slot0, st)));
+    IX_TRY((gemv_fc<WT, KVT, D, B>(h, l, slot0, st)));
+    IX_TRY((gemv_pr<WT, KVT, D, B>(h, l, slot0, st)));
+  }
+  IX_HIP(hipGetLastError());
+  return IXTTS_OK;
+}
+
+static void launch_sampler(ixtts_gpt* h, int n_active, hipStream_t st) {
+  SamplerState s;
+  s.logits = h->logits;
+  s.seen = h->seen;
+  s.tokens = h->tokens;
+  s.gen_count = h->gen_count;
+  s.cur_len = h->cur_len;
+  s.prompt_len = h->prompt_len;
+  s.finished = h->finished;
+  s.forced = h->forced;
+  s.h = h->h;
+  s.mel_emb = A_F32(h->mel_emb);
+  s.mel_pos = A_F32(h->mel_pos);
+  s.cfg = h->d_samp;
+  s.V = h->V;
+  s.D = h->D;
+  s.max_new = h->smax;
+  s.n_pos = h->cfg.n_mel_pos;
+  s.stop = h->cfg.stop_mel_token;
+  s.slot0 = 0;
+  hipLaunchKernelGGL(sampler_greedy_kernel, dim3(n_active), dim3(1024), 0, st, s);
+}
+
+// dispatch on (dtype, D, B)
+#define DISPATCH_B(FN, WT, KVT, DD, B, ...)                 \
+  switch (B) {                                               \
+    case 1: return FN<WT, KVT, DD, 1>(__VA_ARGS__);          \
+    case 2: return FN<WT, KVT, DD, 2>(__VA_ARGS__);          \
+    case 3: return FN<WT, KVT, DD, 3>(__VA_ARGS__);          \
+    case 4: return FN<WT, KVT, DD, 4>(__VA_ARGS__);          \
+    default: set_error("batch %d unsupported (1..4)", B); return IXTTS_ERR_ARG; \
+  }
+#define DISPATCH(FN, h, B, ...)                                                              \
+  do {                                                                                       \
+    if ((h)->cfg.weight_dtype == IXTTS_DTYPE_F32) {                                          \
+      if ((h)->D == 1280) { DISPATCH_B(FN, float, float, 1280, B, __VA_ARGS__) }             \
+      else { DISPATCH_B(FN, float, float, 128, B, __VA_ARGS__) }                             \
+    } else {                                                                                 \
+      if ((h)->D == 1280) { DISPATCH_B(FN, bf16, bf16, 1280, B, __VA_ARGS__) }               \
+      else { DISPATCH_B(FN, bf16, bf16, 128, B, __VA_ARGS__) }                               \
+    }                                                                                        \
+  } while (0)
+
+static int do_forward_layers(ixtts_gpt* h, int B, int slot0, hipStream_t st) { DISPATCH(forward_layers, h, B, h, slot0, st); }
+static int do_head(ixtts_gpt* h, int B, int slot0, float* norm_out, hipStream_t st) { DISPATCH(gemv_head, h, B, h, slot0, norm_out, st); }
+static int do_gemv_which(ixtts_gpt* h, int which, int l, int B, hipStream_t st) {
+  switch (which) {
+    case 0: DISPATCH(gemv_qkv, h, B, h, l, 0, st);
+    case 1: DISPATCH(gemv_out, h, B, h, l, 0, st);
+    case 2: DISPATCH(gemv_fc, h, B, h, l, 0, st);
+    case 3: DISPATCH(gemv_pr, h, B, h, l, 0, st);
+    case 4: DISPATCH(gemv_head, h, B, h, 0, nullptr, st);
+  }
+  set_error("bench_gemv: which=%d", which);
+  return IXTTS_ERR_ARG;
+}
+
+// ------------------------------------------------------------------------------------ create
+static size_t take(size_t& off, size_t bytes) {
+  size_t o = off;
+  off = align_up(off + bytes, 256);
+  return o;
+}
+
+extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
+  IX_ARG(out && c, "gpt_create: null argument");
+  IX_ARG(c->model_dim == 1280 || c->model_dim == 128, "gpt_create: model_dim %d has no kernel instantiation (1280 | 128)", c->model_dim);
+  IX_ARG(c->heads * HD == c->model_dim, "gpt_create: head dim must be 64 (heads %d, dim %d)", c->heads, c->model_dim);
+  IX_ARG(c->layers > 0 && c->n_mel_codes > 0 && c->n_mel_pos > 2 && c->max_seq > 8, "gpt_create: bad sizes");
+  IX_ARG(c->max_batch >= 1 && c->max_batch <= MAXB, "gpt_create: max_batch %d (1..%d)", c->max_batch, MAXB);
+  IX_ARG(c->weight_dtype == IXTTS_DTYPE_F32 || c->weight_dtype == IXTTS_DTYPE_BF16, "gpt_create: weight_dtype");
+  IX_ARG(c->start_mel_token >= 0 && c->start_mel_token < c->n_mel_codes && c->stop_mel_token >= 0 && c->stop_mel_token < c->n_mel_codes, "gpt_create: start/stop token out of range");
+  auto* h = new (std::nothrow) ixtts_gpt();
+  if (!h) return IXTTS_ERR_NOMEM;
+  h->cfg = *c;
+  h->D = c->model_dim;
+  h->L = c->layers;
+  h->H = c->heads;
+  h->V = c->n_mel_codes;
+  h->FF = 4 * h->D;
+  h->slots = c->max_batch + 1;  // last slot: scratch sequence for the latent pass
+  h->smax = c->max_seq;
+  h->esize = c->weight_dtype == IXTTS_DTYPE_F32 ? 4 : 2;
+  const int D = h->D, FF = h->FF, V = h->V;
+  const size_t es = h->esize;
+  size_t off = 0;
+  auto reg = [&](const std::string& name, size_t o, int kind, int64_t d0, int64_t d1) {
+    TDesc t;
+    t.off = o;
+    t.kind = kind;
+    t.d0 = d0;
+    t.d1 = d1;
+    h->tens[name] = t;
+  };
+  h->lo.resize(h->L);
+  for (int l = 0; l < h->L; ++l) {
+    LayerOff& o = h->lo[l];
+    std::string p = "gpt.h." + std::to_string(l) + ".";
+    o.ln1_w = take(off, D * 4); reg(p + "ln_1.weight", o.ln1_w, T_VEC, D, 0);
+    o.ln1_b = take(off, D * 4); reg(p + "ln_1.bias", o.ln1_b, T_VEC, D, 0);
+    o.wqkv = take(off, (size_t)3 * D * D * es); reg(p + "attn.c_attn.weight", o.wqkv, T_MAT_T, D, 3 * D);
+    o.bqkv = take(off, 3 * D * 4); reg(p + "attn.c_attn.bias", o.bqkv, T_VEC, 3 * D, 0);
+    o.wo = take(off, (size_t)D * D * es); reg(p + "attn.c_proj.weight", o.wo, T_MAT_T, D, D);
+    o.bo = take(off, D * 4); reg(p + "attn.c_proj.bias", o.bo, T_VEC, D, 0);
+    o.ln2_w = take(off, D * 4); reg(p + "ln_2.weight", o.ln2_w, T_VEC, D, 0);
+    o.ln2_b = take(off, D * 4); reg(p + "ln_2.bias", o.ln2_b, T_VEC, D, 0);
+    o.wfc = take(off, (size_t)FF * D * es); reg(p + "mlp.c_fc.weight", o.wfc, T_MAT_T, D, FF);
+    o.bfc = take(off, FF * 4); reg(p + "mlp.c_fc.bias", o.bfc, T_VEC, FF, 0);
+    o.wpr = take(off, (size_t)D * FF * es); reg(p + "mlp.c_proj.weight", o.wpr, T_MAT_T, FF, D);
+    o.bpr = take(off, D * 4); reg(p + "mlp.c_proj.bias", o.bpr, T_VEC, D, 0);
+  }
+  h->lnf_w = take(off, D * 4); reg("gpt.ln_f.weight", h->lnf_w, T_VEC, D, 0);
+  h->lnf_b = take(off, D * 4); reg("gpt.ln_f.bias", h->lnf_b, T_VEC, D, 0);
+  h->fn_w = take(off, D * 4); reg("final_norm.weight", h->fn_w, T_VEC, D, 0);
+  h->fn_b = take(off, D * 4); reg("final_norm.bias", h->fn_b, T_VEC, D, 0);
+  h->whead = take(off, (size_t)V * D * es); reg("mel_head.weight", h->whead, T_MAT_N, V, D);
+  h->bhead = take(off, V * 4); reg("mel_head.bias", h->bhead, T_VEC, V, 0);
+  h->mel_emb = take(off, (size_t)V * D * 4); reg("mel_embedding.weight", h->mel_emb, T_EMB, V, D);
+  h->mel_pos = take(off, (size_t)c->n_mel_pos * D * 4); reg("mel_pos_embedding.emb.weight", h->mel_pos, T_EMB, c->n_mel_pos, D);
+  h->arena_bytes = off;
+
+  auto fail = [&](const char* what) {
+    set_error("gpt_create: allocation failed (%s)", what);
+    ixtts_gpt_destroy(h);
+    return IXTTS_ERR_NOMEM;
+  };
+  if (hipMalloc(&h->arena, h->arena_bytes) != hipSuccess) return fail("arena");
+  const int S = h->slots;
+  const size_t kvb = (size_t)h->L * S * D * h->smax * es;
+  if (hipMalloc(&h->kc, kvb) != hipSuccess || hipMalloc(&h->vc, kvb) != hipSuccess) return fail("kv cache");
+  bool ok = true;
+  ok &= hipMalloc(&h->h, (size_t)S * D * 4) == hipSuccess;
+  ok &= hipMalloc(&h->q, (size_t)S * D * 4) == hipSuccess;
+  ok &= hipMalloc(&h->ff, (size_t)S * FF * 4) == hipSuccess;
+  ok &= hipMalloc(&h->part, (size_t)S * h->H * NSPLIT_MAX * PART_STRIDE * 4) == hipSuccess;
+  ok &= hipMalloc(&h->logits, (size_t)S * V * 4) == hipSuccess;
+  ok &= hipMalloc(&h->rowbuf, (size_t)D * 4) == hipSuccess;
+  ok &= hipMalloc(&h->cur_len, S * 4) == hipSuccess;
+  ok &= hipMalloc(&h->gen_count, S * 4) == hipSuccess;
+  ok &= hipMalloc(&h->prompt_len, S * 4) == hipSuccess;
+  ok &= hipMalloc(&h->valid_from, S * 4) == hipSuccess;
+  ok &= hipMalloc(&h->finished, S * 4) == hipSuccess;
+  ok &= hipMalloc(&h->forced, S * 4) == hipSuccess;
+  ok &= hipMalloc(&h->tokens, (size_t)S * h->smax * 4) == hipSuccess;
+  ok &= hipMalloc(&h->seen, (size_t)S * V) == hipSuccess;
+  ok &= hipMalloc(&h->d_samp, sizeof(ixtts_sampler_cfg)) == hipSuccess;
+  h->scratch_floats = (size_t)std::max<size_t>((size_t)V * D, (size_t)FF * D);
+  ok &= hipMalloc(&h->scratch, h->scratch_floats * 4) == hipSuccess;
+  if (!ok) return fail("state");
+  hipMemset(h->cur_len, 0, S * 4);
+  hipMemset(h->gen_count, 0, S * 4);
+  hipMemset(h->prompt_len, 0, S * 4);
+  hipMemset(h->valid_from, 0, S * 4);
+  hipMemset(h->finished, 0, S * 4);
+  hipMemset(h->forced, 0xff, S * 4);
+  hipMemset(h->seen, 0, (size_t)S * V);
+  hipMemset(h->logits, 0, (size_t)S * V * 4);
+  if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
+  // split-S so that heads*splits*B ~ one workgroup per CU
+  for (int b = 1; b <= MAXB; ++b) {
+    int ns = 256 / (h->H * b);
+    h->nsplit[b] = std::max(1, std::min(NSPLIT_MAX, ns));
+  }
+  memset(h->host_prompt_len, 0, sizeof(h->host_prompt_len));
+  memset(h->host_gen_est, 0, sizeof(h->host_gen_est));
+  *out = h;
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_gpt_set_tensor(ixtts_gpt* h, const char* name, const float* data, const int64_t* shape, int ndim) {
+  IX_ARG(h && name && data && shape, "gpt_set_tensor: null argument");
+  auto it = h->tens.find(name);
+  if (it == h->tens.end()) {
+    set_error("gpt_set_tensor: unknown tensor '%s'", name);
+    return IXTTS_ERR_NAME;
+  }
+  TDesc& t = it->second;
+  if (t.kind == T_VEC) {
+    IX_ARG(ndim == 1 && shape[0] == t.d0, "gpt_set_tensor: %s expects [%lld]", name, (long long)t.d0);
+    IX_HIP(hipMemcpy(h->arena + t.off, data, t.d0 * 4, hipMemcpyHostToDevice));
+  } else {
+    IX_ARG(ndim == 2 && shape[0] == t.d0 && shape[1] == t.d1, "gpt_set_tensor: %s expects [%lld,%lld]", name, (long long)t.d0, (long long)t.d1);
+    const size_t n = (size_t)t.d0 * t.d1;
+    if (t.kind == T_EMB) {
+      IX_HIP(hipMemcpy(h->arena + t.off, data, n * 4, hipMemcpyHostToDevice));
+    } else {
+      IX_ARG(n <= h->scratch_floats, "gpt_set_tensor: %s larger than the upload buffer", name);
+      IX_HIP(hipMemcpy(h->scratch, data, n * 4, hipMemcpyHostToDevice));
+      if (t.kind == T_MAT_T) {  // Conv1D weight [K][N] -> Wt[N][K]
+        const int K = (int)t.d0, N = (int)t.d1;
+        dim3 grid(ceil_div(N, 32), ceil_div(K, 32)), blk(32, 8);
+        if (h->esize == 4) hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, blk, 0, 0, h->scratch, (float*)(h->arena + t.off), K, N);
+        else hipLaunchKernelGGL(pack_transpose_kernel<bf16>, grid, blk, 0, 0, h->scratch, (bf16*)(h->arena + t.off), K, N);
+      } else {  // nn.Linear weight [N][K]: already row-per-output
+        if (h->esize == 4) hipLaunchKernelGGL(pack_convert_kernel<float>, dim3(1024), dim3(256), 0, 0, h->scratch, (float*)(h->arena + t.off), n);
+        else hipLaunchKernelGGL(pack_convert_kernel<bf16>, dim3(1024), dim3(256), 0, 0, h->scratch, (bf16*)(h->arena + t.off), n);
+      }
+      IX_HIP(hipGetLastError());
+      IX_HIP(hipDeviceSynchronize());
+    }
+  }
+  t.set = true;
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_gpt_finalize(ixtts_gpt* h) {
+  IX_ARG(h, "gpt_finalize: null handle");
+  for (auto& kv : h->tens)
+    if (!kv.second.set) {
+      set_error("gpt_finalize: tensor '%s' was not supplied", kv.first.c_str());
+      return IXTTS_ERR_STATE;
+    }
+  h->finalized = true;
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_gpt_arena(ixtts_gpt* h, void** ptr, size_t* bytes) {
+  IX_ARG(h && ptr && bytes, "gpt_arena: null argument");
+  *ptr = h->arena;
+  *bytes = h->arena_bytes;
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_gpt_adopt_arena(ixtts_gpt* h) {
+  IX_ARG(h, "gpt_adopt_arena: null handle");
+  for (auto& kv : h->tens) kv.second.set = true;
+  h->finalized = true;
+  return IXTTS_OK;
+}
+
+#define NEED_READY(h, who)                                       \
+  do {                                                           \
+    IX_ARG(h, who ": null handle");                              \
+    if (!(h)->finalized) {                                       \
+      set_error(who ": weights not finalized");                  \
+      return IXTTS_ERR_STATE;                                    \
+    }                                                            \
+  } while (0)
+
+// ------------------------------------------------------------------------------------ prefill
+extern "C" int ixtts_gpt_prefill(ixtts_gpt* h, int b, const float* embeds, int n_rows, int n_left_pad, void* stream) {
+  NEED_READY(h, "gpt_prefill");
+  IX_ARG(b >= 0 && b < h->cfg.max_batch, "gpt_prefill: slot %d out of range", b);
+  IX_ARG(embeds && n_rows >= 1 && n_left_pad >= 0 && n_left_pad < n_rows, "gpt_prefill: bad rows (%d, pad %d)", n_rows, n_left_pad);
+  IX_ARG(n_rows + 2 < h->smax, "gpt_prefill: prompt of %d rows exceeds max_seq %d", n_rows + 1, h->smax);
+  hipStream_t st = (hipStream_t)stream;
+  const int D = h->D, V = h->V;
+  // slot state: history = fake ids [1]*(P-1) + [start]  (model_v2.py:652-661)
+  IX_HIP(hipMemsetAsync(h->seen + (size_t)b * V, 0, V, st));
+  IX_HIP(hipMemsetAsync(h->seen + (size_t)b * V + 1, 1, 1, st));
+  IX_HIP(hipMemsetAsync(h->seen + (size_t)b * V + h->cfg.start_mel_token, 1, 1, st));
+  IX_HIP(hipMemsetAsync(h->gen_count + b, 0, 4, st));
+  IX_HIP(hipMemsetAsync(h->finished + b, 0, 4, st));
+  IX_HIP(hipMemsetAsync(h->forced + b, 0xff, 4, st));
+  const int P = n_rows + 1;
+  IX_HIP(hipMemcpyAsync(h->prompt_len + b, &P, 4, hipMemcpyHostToDevice, st));
+  IX_HIP(hipMemcpyAsync(h->valid_from + b, &n_left_pad, 4, hipMemcpyHostToDevice, st));
+  h->host_prompt_len[b] = P;
+  h->host_gen_est[b] = 0;
+  // Row-by-row causal pass through the decode kernels (left-pad rows are never attended
+  // to -- valid_from masks them as keys -- so they are skipped outright).
+  for (int r = n_left_pad; r < P; ++r) {
+    if (r < n_rows) {
+      hipLaunchKernelGGL(set_row_kernel, dim3(4), dim3(256), 0, st, h->h, embeds + (size_t)r * D, (const float*)nullptr, D, b, h->cur_len, r);
+    } else {  // start_mel_token row: mel_embedding[start] + mel_pos_embedding[0]
+      hipLaunchKernelGGL(set_row_kernel, dim3(4), dim3(256), 0, st, h->h, A_F32(h->mel_emb) + (size_t)h->cfg.start_mel_token * D,
+                         (const float*)A_F32(h->mel_pos), D, b, h->cur_len, r);
+    }
+    IX_TRY(do_forward_layers(h, 1, b, st));
+  }
+  IX_TRY(do_head(h, 1, b, nullptr, st));
+  IX_HIP(hipGetLastError());
+  return IXTTS_OK;
+}
+
+// ------------------------------------------------------------------------------------ decode
+static int build_step_graph(ixtts_gpt* h, int B) {
+  hipGraph_t g;
+  hipStream_t cs = h->cap_stream;
+  IX_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+  launch_sampler(h, B, cs);
+  int rc = do_forward_layers(h, B, 0, cs);
+  if (rc == IXTTS_OK) rc = do_head(h, B, 0, nullptr, cs);
+  hipError_t e = hipStreamEndCapture(cs, &g);
+  if (rc != IXTTS_OK) return rc;
+  IX_HIP(e);
+  IX_HIP(hipGraphInstantiate(&h->step_exec[B], g, nullptr, nullptr, 0));
+  IX_HIP(hipGraphDestroy(g));
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_gpt_decode(ixtts_gpt* h, int n_active, int n_steps, const ixtts_sampler_cfg* sc, void* stream) {
+  NEED_READY(h, "gpt_decode");
+  IX_ARG(sc, "gpt_decode: null sampler cfg");
+  IX_ARG(n_active >= 1 && n_active <= h->cfg.max_batch, "gpt_decode: n_active %d", n_active);
+  IX_ARG(n_steps >= 0, "gpt_decode: n_steps %d", n_steps);
+  if (sc->do_sample) {
+    set_error("gpt_decode: do_sample=1 (top-k/top-p multinomial) is not implemented in this build");
+    return IXTTS_ERR_ARG;
+  }
+  for (int b = 0; b < n_active; ++b) {
+    IX_ARG(h->host_prompt_len[b] > 0, "gpt_decode: slot %d has no prefilled prompt", b);
+    IX_ARG(h->host_prompt_len[b] + h->host_gen_est[b] + n_steps < h->smax, "gpt_decode: slot %d would overflow max_seq %d", b, h->smax);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (!h->step_exec[n_active]) {
+    // warm the kernels' one-time attribute setup outside capture by a dry eager launch is not
+    // needed: hipFuncSetAttribute is legal during capture of another stream.
+    IX_TRY(build_step_graph(h, n_active));
+  }
+  h->samp_host = *sc;
+  IX_HIP(hipMemcpyAsync(h->d_samp, &h->samp_host, sizeof(ixtts_sampler_cfg), hipMemcpyHostToDevice, st));
+  for (int i = 0; i < n_steps; ++i) IX_HIP(hipGraphLaunch(h->step_exec[n_active], st));
+  for (int b = 0; b < n_active; ++b) h->host_gen_est[b] += n_steps;
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_gpt_read(ixtts_gpt* h, int b, int32_t* ids, int cap, int* n_ids, int* finished, void* stream) {
+  NEED_READY(h, "gpt_read");
+  IX_ARG(b >= 0 && b < h->cfg.max_batch && ids && n_ids && finished && cap >= 0, "gpt_read: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  IX_HIP(hipStreamSynchronize(st));
+  int gc = 0, fin = 0;
+  IX_HIP(hipMemcpy(&gc, h->gen_count + b, 4, hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(&fin, h->finished + b, 4, hipMemcpyDeviceToHost));
+  int n = std::min(gc, std::min(cap, h->smax));
+  if (n > 0) IX_HIP(hipMemcpy(ids, h->tokens + (size_t)b * h->smax, (size_t)n * 4, hipMemcpyDeviceToHost));
+  int len = n;
+  for (int i = 0; i < n; ++i)
+    if (ids[i] == h->cfg.stop_mel_token) {
+      len = i + 1;
+      break;
+    }
+  *n_ids = len;
+  *finished = fin;
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_gpt_read_logits(ixtts_gpt* h, int b, float* out, void* stream) {
+  NEED_READY(h, "gpt_read_logits");
+  IX_ARG(b >= 0 && b < h->cfg.max_batch && out, "gpt_read_logits: bad argument");
+  IX_HIP(hipStreamSynchronize((hipStream_t)stream));
+  IX_HIP(hipMemcpy(out, h->logits + (size_t)b * h->V, (size_t)h->V * 4, hipMemcpyDeviceToHost));
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_gpt_force_next(ixtts_gpt* h, int b, int32_t token, void* stream) {
+  NEED_READY(h, "gpt_force_next");
+  IX_ARG(b >= 0 && b < h->cfg.max_batch && token >= 0 && token < h->V, "gpt_force_next: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  IX_HIP(hipMemcpyAsync(h->forced + b, &token, 4, hipMemcpyHostToDevice, st));
+  IX_HIP(hipStreamSynchronize(st));
+  return IXTTS_OK;
+}
+
+// ------------------------------------------------------------------------------------ latent pass
+namespace ixtts {
+__global__ void embed_code_row_kernel(float* h, const float* mel_emb, const float* mel_pos, const int32_t* codes, int idx,
+                                      int fixed_tok, int pos, int D, int slot, int* cur_len, int kvpos) {
+  const int tok = (fixed_tok >= 0) ? fixed_tok : codes[idx];
+  for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < D; i += blockDim.x * gridDim.x)
+    h[(size_t)slot * D + i] = mel_emb[(size_t)tok * D + i] + mel_pos[(size_t)pos * D + i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) cur_len[slot] = kvpos;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void final_norm_row_kernel(const float* h, const float* w1, const float* b1, const float* w2,
+                                                              const float* b2, float* out) {
+  __shared__ float xs[K];
+  __shared__ float red[4];
+  for (int i = threadIdx.x; i < K; i += 256) xs[i] = h[i];
+  __syncthreads();
+  layer_norm_lds<K>(xs, w1, b1, red);
+  layer_norm_lds<K>(xs, w2, b2, red);
+  for (int i = threadIdx.x; i < K; i += 256) out[i] = xs[i];
+}
+}  // namespace ixtts
+
+extern "C" int ixtts_gpt_latent(ixtts_gpt* h, const float* prefix, int n_prefix, const int32_t* codes, int n, float* latent,
+                                void* stream) {
+  NEED_READY(h, "gpt_latent");
+  IX_ARG(prefix && n_prefix >= 1 && n >= 0 && (codes || n == 0) && (latent || n == 0), "gpt_latent: bad argument");
+  IX_ARG(n + 2 <= h->cfg.n_mel_pos, "gpt_latent: %d codes exceed the mel position table", n);
+  IX_ARG(n_prefix + n + 2 < h->smax, "gpt_latent: sequence of %d rows exceeds max_seq %d", n_prefix + n + 2, h->smax);
+  if (n == 0) return IXTTS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int D = h->D;
+  const int slot = h->slots - 1;  // scratch sequence
+  const int zero = 0;
+  IX_HIP(hipMemcpyAsync(h->valid_from + slot, &zero, 4, hipMemcpyHostToDevice, st));
+  const int total = n_prefix + n + 2;
+  // Only the first n mel rows are returned ([:-2], model_v2.py:596) and the pass is causal,
+  // so the two trailing rows (last code, stop) need not be computed at all.
+  const int rows = n_prefix + n;
+  (void)total;
+  for (int r = 0; r < rows; ++r) {
+    if (r < n_prefix) {
+      hipLaunchKernelGGL(set_row_kernel, dim3(4), dim3(256), 0, st, h->h, prefix + (size_t)r * D, (const float*)nullptr, D, slot, h->cur_len, r);
+    } else {
+      const int mi = r - n_prefix;  // mel row index: 0 -> start token, i -> codes[i-1]
+      hipLaunchKernelGGL(embed_code_row_kernel, dim3(4), dim3(256), 0, st, h->h, (const float*)A_F32(h->mel_emb), (const float*)A_F32(h->mel_pos), codes,
+                         mi - 1, mi == 0 ? h->cfg.start_mel_token : -1, mi, D, slot, h->cur_len, r);
+    }
+    IX_TRY(do_forward_layers(h, 1, slot, st));
+    if (r >= n_prefix) {
+      float* dst = latent + (size_t)(r - n_prefix) * D;
+      const float* src = h->h + (size_t)slot * D;
+      if (D == 1280)
+        hipLaunchKernelGGL(final_norm_row_kernel<1280>, dim3(1), dim3(256), 0, st, src, (const float*)A_F32(h->lnf_w), (const float*)A_F32(h->lnf_b), (const float*)A_F32(h->fn_w), (const float*)A_F32(h->fn_b), dst);
+      else
+        hipLaunchKernelGGL(final_norm_row_kernel<128>, dim3(1), dim3(256), 0, st, src, (const float*)A_F32(h->lnf_w), (const float*)A_F32(h->lnf_b), (const float*)A_F32(h->fn_w), (const float*)A_F32(h->fn_b), dst);
+    }
+  }
+  IX_HIP(hipGetLastError());
+  return IXTTS_OK;
+}
+
+// ------------------------------------------------------------------------------------ bench hooks
+extern "C" int ixtts_gpt_bench_gemv(ixtts_gpt* h, int which, int layer, int batch, void* stream) {
+  NEED_READY(h, "gpt_bench_gemv");
+  IX_ARG(layer >= 0 && layer < h->L && batch >= 1 && batch <= h->cfg.max_batch, "gpt_bench_gemv: bad argument");
+  return do_gemv_which(h, which, layer, batch, (hipStream_t)stream);
+}
+
+extern "C" double ixtts_gpt_step_bytes(const ixtts_gpt* h, int B, int S) {
+  if (!h) return 0.0;
+  const double D = h->D, FF = h->FF, V = h->V, L = h->L, es = (double)h->esize;
+  double mat = L * (3 * D * D + D * D + 2 * D * FF) + V * D;
+  double vec = L * (2 * D + 3 * D + D + 2 * D + FF + D) + 4 * D + V;
+  double kv_read = (double)B * 2 * L * S * D * es;
+  double kv_write = (double)B * 2 * L * D * es;
+  double emb = (double)B * 2 * D * 4;
+  return mat * es + vec * 4 + kv_read + kv_write + emb;
+}
+
+extern "C" int ixtts_gpt_destroy(ixtts_gpt* h) {
+  if (!h) return IXTTS_OK;
+  for (int b = 0; b <= MAXB; ++b)
+    if (h->step_exec[b]) hipGraphExecDestroy(h->step_exec[b]);
+  if (h->cap_stream) hipStreamDestroy(h->cap_stream);
+  void* ptrs[] = {h->arena, h->kc, h->vc, h->h, h->q, h->ff, h->part, h->logits, h->rowbuf, h->cur_len, h->gen_count,
+                  h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->scratch};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  delete h;
+  return IXTTS_OK;
 }
