@@ -61,3 +61,42 @@ if "gpt" in what:
             ids, fin = eng.read(0)
             print("   ids", ids[:8].tolist(), len(ids))
             del eng
+
+if "micro" in what:
+    # per-kernel cost inside a graph, un-profiled: 24 layers x kind, replayed
+    W = WR.make_gpt_weights(WR.GPT_CFG, seed=1234)
+    for dtype in ("bf16", "f32"):
+        eng = GptEngine(WR.GPT_CFG, dtype=dtype, max_seq=2048, max_batch=2, device=dev).load_state_dict(W)
+        emb = torch.randn(136, 1280, generator=torch.Generator().manual_seed(1)) * 0.5
+        eng.prefill(0, emb, 0)
+        eng.prefill(1, emb, 0)
+        es = 2 if dtype == "bf16" else 4
+        sizes = {0: 3 * 1280 * 1280 * es, 1: 1280 * 1280 * es, 2: 4 * 1280 * 1280 * es, 3: 4 * 1280 * 1280 * es, 4: 8194 * 1280 * es}
+        names = {0: "qkv", 1: "out", 2: "fc", 3: "mlp_out", 4: "head"}
+        s = torch.cuda.Stream()
+        for B in (1, 2):
+            for which in range(5):
+                with torch.cuda.stream(s):
+                    for l in range(24):
+                        eng.bench_gemv(which, l, B)
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=s):
+                        for l in range(24):
+                            eng.bench_gemv(which, l if which < 4 else 0, B)
+                    g.replay()
+                    ms = ev_time(lambda: g.replay(), 20) / 24
+                print(f"micro {dtype} B={B} {names[which]:8s}: {ms*1e3:6.2f} us/kernel  {sizes[which]/ms/1e6:7.0f} GB/s", flush=True)
+        del eng
+    x = torch.zeros(64, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        x.add_(1)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(200):
+                x.add_(1)
+        g.replay()
+        ms = ev_time(lambda: g.replay(), 20) / 200
+    print(f"micro trivial kernel in graph: {ms*1e3:.2f} us", flush=True)

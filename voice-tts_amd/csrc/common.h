@@ -49,11 +49,26 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
 __device__ __forceinline__ float lo_bf16(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float hi_bf16(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
 
-// 64-lane butterfly sum; every lane ends with the total (fixed order -> deterministic)
+// ---- wavefront reductions on DPP (no LDS crossbar): fixed order -> bit-reproducible.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_take(float v) {
+  // lanes disabled by the masks / reading out of range receive 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, true));
+}
+// total lands in lane 63
+__device__ __forceinline__ float wave_sum63(float v) {
+  float s = v + dpp_take<0x111, 0xf, 0xf>(v);  // row_shr:1
+  s += dpp_take<0x112, 0xf, 0xf>(v);           // row_shr:2
+  s += dpp_take<0x113, 0xf, 0xf>(v);           // row_shr:3
+  s += dpp_take<0x114, 0xf, 0xe>(s);           // row_shr:4
+  s += dpp_take<0x118, 0xf, 0xc>(s);           // row_shr:8
+  s += dpp_take<0x142, 0xa, 0xf>(s);           // row_bcast:15
+  s += dpp_take<0x143, 0xc, 0xf>(s);           // row_bcast:31
+  return s;
+}
+// every lane ends with the total
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum63(v)), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

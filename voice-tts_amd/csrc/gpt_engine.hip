@@ -31,6 +31,7 @@ struct TDesc {
   size_t off = 0;  // byte offset in the arena
   int kind = T_VEC;
   int64_t d0 = 0, d1 = 0;  // expected shape ([d0] or [d0][d1] as in the state dict)
+  size_t stage_off = 0;    // float offset in the fp32 staging arena (matrices only)
   bool set = false;
 };
 
@@ -62,7 +63,9 @@ struct ixtts_gpt {
   std::map<std::string, TDesc> tens;
   bool finalized = false;
   // state
-  float *h = nullptr, *q = nullptr, *ff = nullptr, *part = nullptr, *logits = nullptr, *rowbuf = nullptr;
+  float *h = nullptr, *q = nullptr, *ff = nullptr, *att = nullptr, *logits = nullptr, *rowbuf = nullptr;
+  float* stage = nullptr;  // fp32 [N][K] staging of every matrix until finalize folds/converts it
+  size_t stage_floats = 0;
   void *kc = nullptr, *vc = nullptr;
   int *cur_len = nullptr, *gen_count = nullptr, *prompt_len = nullptr, *valid_from = nullptr, *finished = nullptr,
       *forced = nullptr;
@@ -74,7 +77,6 @@ struct ixtts_gpt {
   size_t scratch_floats = 0;
   hipStream_t cap_stream = nullptr;
   hipGraphExec_t step_exec[MAXB + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  int nsplit[MAXB + 1];
   int host_prompt_len[MAXB + 2];
   int host_gen_est[MAXB + 2];
 };
@@ -85,7 +87,16 @@ struct ixtts_gpt {
 // ------------------------------------------------------------------------------------ launch helpers
 template <typename WT, typename KVT, int K, int ROWS, int UNITS, int B, int INP, int EPI>
 static int launch_gemv(const GemvArgs& a, hipStream_t st) {
-  auto kern = gemv_kernel<WT, K, ROWS, UNITS, B, INP, EPI, KVT>;
+  auto kern = gemv_reg_kernel<WT, K, ROWS, UNITS, B, INP, EPI, KVT>;
+  const int n_units = (a.N + ROWS - 1) / ROWS;
+  const int grid = ceil_div(n_units, 4 * UNITS);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a);
+  return IXTTS_OK;
+}
+
+template <typename WT, typename KVT, int K, int ROWS, int UNITS, int B, int EPI>
+static int launch_gemv_lds(const GemvArgs& a, hipStream_t st) {
+  auto kern = gemv_lds_kernel<WT, K, ROWS, UNITS, B, EPI, KVT>;
   const size_t smem = (size_t)B * K * sizeof(float);
   if (smem > 64 * 1024) {
     static bool done = false;
@@ -111,8 +122,6 @@ static int gemv_qkv(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.N = 3 * D;
   a.slot0 = slot0;
   a.xin = h->h;
-  a.ln_w = A_F32(o.ln1_w);
-  a.ln_b = A_F32(o.ln1_b);
   a.out = h->q;
   a.out_stride = D;
   const size_t lstride = (size_t)h->slots * D * h->smax * sizeof(KVT);
@@ -134,11 +143,10 @@ static int gemv_out(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.bias = A_F32(o.bo);
   a.N = D;
   a.slot0 = slot0;
-  a.xin = h->part;
-  a.nsplit = h->nsplit[B];
+  a.xin = h->att;
   a.out = h->h;
   a.out_stride = D;
-  return launch_gemv<WT, KVT, D, DM::R1, DM::U_OUT, B, IN_ATTN, EPI_RESID>(a, st);
+  return launch_gemv<WT, KVT, D, DM::R1, DM::U_OUT, B, IN_PLAIN, EPI_RESID>(a, st);
 }
 
 template <typename WT, typename KVT, int D, int B>
@@ -152,8 +160,6 @@ static int gemv_fc(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.N = 4 * D;
   a.slot0 = slot0;
   a.xin = h->h;
-  a.ln_w = A_F32(o.ln2_w);
-  a.ln_b = A_F32(o.ln2_b);
   a.out = h->ff;
   a.out_stride = 4 * D;
   return launch_gemv<WT, KVT, D, DM::R1, DM::U_FC, B, IN_LN, EPI_GELU>(a, st);
@@ -172,7 +178,7 @@ static int gemv_pr(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.xin = h->ff;
   a.out = h->h;
   a.out_stride = D;
-  return launch_gemv<WT, KVT, 4 * D, DM::R4, DM::U_PR, B, IN_PLAIN, EPI_RESID>(a, st);
+  return launch_gemv_lds<WT, KVT, 4 * D, DM::R4, DM::U_PR, B, EPI_RESID>(a, st);
 }
 
 template <typename WT, typename KVT, int D, int B>
@@ -187,8 +193,6 @@ static int gemv_head(ixtts_gpt* h, int slot0, float* norm_out, hipStream_t st) {
   a.xin = h->h;
   a.ln_w = A_F32(h->lnf_w);
   a.ln_b = A_F32(h->lnf_b);
-  a.ln2_w = A_F32(h->fn_w);
-  a.ln2_b = A_F32(h->fn_b);
   a.out = h->logits;
   a.out_stride = h->V;
   a.norm_out = norm_out;
@@ -204,15 +208,14 @@ static int forward_layers(ixtts_gpt* h, int slot0, hipStream_t st) {
     t.q = h->q;
     t.kcache = (uint8_t*)h->kc + l * lstride;
     t.vcache = (uint8_t*)h->vc + l * lstride;
-    t.part = h->part;
+    t.out = h->att;
     t.cur_len = h->cur_len;
     t.valid_from = h->valid_from;
     t.slot0 = slot0;
     t.heads = h->H;
     t.smax = h->smax;
-    t.nsplit = h->nsplit[B];
     t.D = D;
-    hipLaunchKernelGGL(attn_decode_kernel<KVT>, dim3(h->H, h->nsplit[B], B), dim3(256), 0, st, t);
+    hipLaunchKernelGGL((attn_decode_kernel<KVT, 16>), dim3(h->H, B), dim3(1024), 0, st, t);
     IX_TRY((gemv_out<WT, KVT, D, B>(h, l, slot0, st)));
     IX_TRY((gemv_fc<WT, KVT, D, B>(h, l, slot0, st)));
     IX_TRY((gemv_pr<WT, KVT, D, B>(h, l, slot0, st)));
@@ -307,12 +310,17 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   const int D = h->D, FF = h->FF, V = h->V;
   const size_t es = h->esize;
   size_t off = 0;
+  size_t stage_off = 0;
   auto reg = [&](const std::string& name, size_t o, int kind, int64_t d0, int64_t d1) {
     TDesc t;
     t.off = o;
     t.kind = kind;
     t.d0 = d0;
     t.d1 = d1;
+    if (kind == T_MAT_T || kind == T_MAT_N) {
+      t.stage_off = stage_off;
+      stage_off += (size_t)d0 * d1;
+    }
     h->tens[name] = t;
   };
   h->lo.resize(h->L);
@@ -341,6 +349,7 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   h->mel_emb = take(off, (size_t)V * D * 4); reg("mel_embedding.weight", h->mel_emb, T_EMB, V, D);
   h->mel_pos = take(off, (size_t)c->n_mel_pos * D * 4); reg("mel_pos_embedding.emb.weight", h->mel_pos, T_EMB, c->n_mel_pos, D);
   h->arena_bytes = off;
+  h->stage_floats = stage_off;
 
   auto fail = [&](const char* what) {
     set_error("gpt_create: allocation failed (%s)", what);
@@ -348,6 +357,7 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
     return IXTTS_ERR_NOMEM;
   };
   if (hipMalloc(&h->arena, h->arena_bytes) != hipSuccess) return fail("arena");
+  if (hipMalloc(&h->stage, h->stage_floats * 4) != hipSuccess) return fail("staging arena");
   const int S = h->slots;
   const size_t kvb = (size_t)h->L * S * D * h->smax * es;
   if (hipMalloc(&h->kc, kvb) != hipSuccess || hipMalloc(&h->vc, kvb) != hipSuccess) return fail("kv cache");
@@ -355,7 +365,7 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   ok &= hipMalloc(&h->h, (size_t)S * D * 4) == hipSuccess;
   ok &= hipMalloc(&h->q, (size_t)S * D * 4) == hipSuccess;
   ok &= hipMalloc(&h->ff, (size_t)S * FF * 4) == hipSuccess;
-  ok &= hipMalloc(&h->part, (size_t)S * h->H * NSPLIT_MAX * PART_STRIDE * 4) == hipSuccess;
+  ok &= hipMalloc(&h->att, (size_t)S * D * 4) == hipSuccess;
   ok &= hipMalloc(&h->logits, (size_t)S * V * 4) == hipSuccess;
   ok &= hipMalloc(&h->rowbuf, (size_t)D * 4) == hipSuccess;
   ok &= hipMalloc(&h->cur_len, S * 4) == hipSuccess;
@@ -367,7 +377,7 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   ok &= hipMalloc(&h->tokens, (size_t)S * h->smax * 4) == hipSuccess;
   ok &= hipMalloc(&h->seen, (size_t)S * V) == hipSuccess;
   ok &= hipMalloc(&h->d_samp, sizeof(ixtts_sampler_cfg)) == hipSuccess;
-  h->scratch_floats = (size_t)std::max<size_t>((size_t)V * D, (size_t)FF * D);
+  h->scratch_floats = (size_t)FF * D;
   ok &= hipMalloc(&h->scratch, h->scratch_floats * 4) == hipSuccess;
   if (!ok) return fail("state");
   hipMemset(h->cur_len, 0, S * 4);
@@ -379,11 +389,6 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   hipMemset(h->seen, 0, (size_t)S * V);
   hipMemset(h->logits, 0, (size_t)S * V * 4);
   if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
-  // split-S so that heads*splits*B ~ one workgroup per CU
-  for (int b = 1; b <= MAXB; ++b) {
-    int ns = 256 / (h->H * b);
-    h->nsplit[b] = std::max(1, std::min(NSPLIT_MAX, ns));
-  }
   memset(h->host_prompt_len, 0, sizeof(h->host_prompt_len));
   memset(h->host_gen_est, 0, sizeof(h->host_gen_est));
   *out = h;
@@ -407,32 +412,68 @@ extern "C" int ixtts_gpt_set_tensor(ixtts_gpt* h, const char* name, const float*
     if (t.kind == T_EMB) {
       IX_HIP(hipMemcpy(h->arena + t.off, data, n * 4, hipMemcpyHostToDevice));
     } else {
-      IX_ARG(n <= h->scratch_floats, "gpt_set_tensor: %s larger than the upload buffer", name);
-      IX_HIP(hipMemcpy(h->scratch, data, n * 4, hipMemcpyHostToDevice));
-      if (t.kind == T_MAT_T) {  // Conv1D weight [K][N] -> Wt[N][K]
+      if (!h->stage) {
+        set_error("gpt_set_tensor: %s arrived after finalize", name);
+        return IXTTS_ERR_STATE;
+      }
+      float* dst = h->stage + t.stage_off;
+      if (t.kind == T_MAT_T) {  // Conv1D weight [K][N] -> staging Wt[N][K]
+        IX_ARG(n <= h->scratch_floats, "gpt_set_tensor: %s larger than the upload buffer", name);
+        IX_HIP(hipMemcpy(h->scratch, data, n * 4, hipMemcpyHostToDevice));
         const int K = (int)t.d0, N = (int)t.d1;
         dim3 grid(ceil_div(N, 32), ceil_div(K, 32)), blk(32, 8);
-        if (h->esize == 4) hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, blk, 0, 0, h->scratch, (float*)(h->arena + t.off), K, N);
-        else hipLaunchKernelGGL(pack_transpose_kernel<bf16>, grid, blk, 0, 0, h->scratch, (bf16*)(h->arena + t.off), K, N);
+        hipLaunchKernelGGL(pack_transpose_kernel, grid, blk, 0, 0, h->scratch, dst, K, N);
+        IX_HIP(hipGetLastError());
+        IX_HIP(hipDeviceSynchronize());
       } else {  // nn.Linear weight [N][K]: already row-per-output
-        if (h->esize == 4) hipLaunchKernelGGL(pack_convert_kernel<float>, dim3(1024), dim3(256), 0, 0, h->scratch, (float*)(h->arena + t.off), n);
-        else hipLaunchKernelGGL(pack_convert_kernel<bf16>, dim3(1024), dim3(256), 0, 0, h->scratch, (bf16*)(h->arena + t.off), n);
+        IX_HIP(hipMemcpy(dst, data, n * 4, hipMemcpyHostToDevice));
       }
-      IX_HIP(hipGetLastError());
-      IX_HIP(hipDeviceSynchronize());
     }
   }
   t.set = true;
   return IXTTS_OK;
 }
 
+template <typename WT>
+static int fold_one(ixtts_gpt* h, const char* wname, const float* g, const float* beta, float* bias, size_t dst_off) {
+  const TDesc& t = h->tens.at(wname);
+  // staging is [N][K]: Conv1D tensors were registered as [K][N], nn.Linear as [N][K]
+  const int N = (int)(t.kind == T_MAT_T ? t.d1 : t.d0), K = (int)(t.kind == T_MAT_T ? t.d0 : t.d1);
+  hipLaunchKernelGGL(fold_convert_kernel<WT>, dim3(ceil_div(N, 4)), dim3(256), 0, 0, h->stage + t.stage_off, g, beta, bias,
+                     reinterpret_cast<WT*>(h->arena + dst_off), N, K);
+  IX_HIP(hipGetLastError());
+  return IXTTS_OK;
+}
+
+template <typename WT>
+static int fold_all(ixtts_gpt* h) {
+  for (int l = 0; l < h->L; ++l) {
+    const LayerOff& o = h->lo[l];
+    std::string p = "gpt.h." + std::to_string(l) + ".";
+    // LN gain/bias folded into the matrix they feed: W' = W diag(g), b' = b + W beta
+    IX_TRY(fold_one<WT>(h, (p + "attn.c_attn.weight").c_str(), A_F32(o.ln1_w), A_F32(o.ln1_b), A_F32(o.bqkv), o.wqkv));
+    IX_TRY(fold_one<WT>(h, (p + "attn.c_proj.weight").c_str(), nullptr, nullptr, nullptr, o.wo));
+    IX_TRY(fold_one<WT>(h, (p + "mlp.c_fc.weight").c_str(), A_F32(o.ln2_w), A_F32(o.ln2_b), A_F32(o.bfc), o.wfc));
+    IX_TRY(fold_one<WT>(h, (p + "mlp.c_proj.weight").c_str(), nullptr, nullptr, nullptr, o.wpr));
+  }
+  // final_norm folds into mel_head; ln_f stays explicit (a LayerNorm sits between them)
+  IX_TRY(fold_one<WT>(h, "mel_head.weight", A_F32(h->fn_w), A_F32(h->fn_b), A_F32(h->bhead), h->whead));
+  IX_HIP(hipDeviceSynchronize());
+  return IXTTS_OK;
+}
+
 extern "C" int ixtts_gpt_finalize(ixtts_gpt* h) {
   IX_ARG(h, "gpt_finalize: null handle");
+  if (h->finalized) return IXTTS_OK;
   for (auto& kv : h->tens)
     if (!kv.second.set) {
       set_error("gpt_finalize: tensor '%s' was not supplied", kv.first.c_str());
       return IXTTS_ERR_STATE;
     }
+  if (h->esize == 4) IX_TRY(fold_all<float>(h));
+  else IX_TRY(fold_all<bf16>(h));
+  hipFree(h->stage);
+  h->stage = nullptr;
   h->finalized = true;
   return IXTTS_OK;
 }
@@ -447,6 +488,10 @@ extern "C" int ixtts_gpt_arena(ixtts_gpt* h, void** ptr, size_t* bytes) {
 extern "C" int ixtts_gpt_adopt_arena(ixtts_gpt* h) {
   IX_ARG(h, "gpt_adopt_arena: null handle");
   for (auto& kv : h->tens) kv.second.set = true;
+  if (h->stage) {
+    hipFree(h->stage);
+    h->stage = nullptr;
+  }
   h->finalized = true;
   return IXTTS_OK;
 }
@@ -586,6 +631,31 @@ __global__ void embed_code_row_kernel(float* h, const float* mel_emb, const floa
   if (blockIdx.x == 0 && threadIdx.x == 0) cur_len[slot] = kvpos;
 }
 
+__device__ __forceinline__ float block_sum_256(float v, float* red /*[4]*/) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// LayerNorm of xs[0..K) in place (two-pass, eps 1e-5), all 256 threads participate.
+template <int K>
+__device__ __forceinline__ void layer_norm_lds(float* xs, const float* __restrict__ w, const float* __restrict__ b, float* red) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < K; i += 256) s += xs[i];
+  const float mean = block_sum_256(s, red) * (1.0f / K);
+  float q = 0.f;
+  for (int i = threadIdx.x; i < K; i += 256) {
+    const float d = xs[i] - mean;
+    q += d * d;
+  }
+  const float var = block_sum_256(q, red) * (1.0f / K);
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  for (int i = threadIdx.x; i < K; i += 256) xs[i] = (xs[i] - mean) * rstd * w[i] + b[i];
+  __syncthreads();
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void final_norm_row_kernel(const float* h, const float* w1, const float* b1, const float* w2,
                                                               const float* b2, float* out) {
@@ -661,7 +731,7 @@ extern "C" int ixtts_gpt_destroy(ixtts_gpt* h) {
   for (int b = 0; b <= MAXB; ++b)
     if (h->step_exec[b]) hipGraphExecDestroy(h->step_exec[b]);
   if (h->cap_stream) hipStreamDestroy(h->cap_stream);
-  void* ptrs[] = {h->arena, h->kc, h->vc, h->h, h->q, h->ff, h->part, h->logits, h->rowbuf, h->cur_len, h->gen_count,
+  void* ptrs[] = {h->arena, h->stage, h->kc, h->vc, h->h, h->q, h->ff, h->att, h->logits, h->rowbuf, h->cur_len, h->gen_count,
                   h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->scratch};
   for (void* p : ptrs)
     if (p) hipFree(p);

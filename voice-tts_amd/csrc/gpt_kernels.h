@@ -1,11 +1,19 @@
 // gpt_kernels.h -- device kernels of the GPT-2 decode step on gfx950 (rows G1-G8).
 //
-// One decode step = [sampler+embed] -> 24 x {LN1+QKV GEMV (+KV append) | split-S attention |
-// combine+out-proj GEMV (+residual) | LN2+FC GEMV (+gelu_new) | MLP-out GEMV (+residual)} ->
-// ln_f + final_norm + head GEMV.  Every kernel is HBM-bandwidth-shaped: weights are streamed
-// exactly once per step as 16-byte-per-lane coalesced loads straight into VGPRs (no LDS round
-// trip for a read-once operand), the activation vector lives in LDS, reductions are
-// fixed-order wavefront butterflies (bit-reproducible run to run).
+// One decode step = [sampler+embed] -> 24 x {LN1+QKV GEMV (+KV append) | single-query attention |
+// out-proj GEMV (+residual) | LN2+FC GEMV (+gelu_new) | MLP-out GEMV (+residual)} ->
+// ln_f + final_norm + head GEMV.  Every kernel is HBM-bandwidth/latency-shaped:
+//   * weights are stored transposed ([N][K], K contiguous) and streamed exactly once per step
+//     as 16-byte-per-lane coalesced loads straight into VGPRs (a read-once operand gains
+//     nothing from an LDS round trip); they are issued FIRST-but-one so they fly across the
+//     whole prologue;
+//   * each wavefront is independent: it owns ROWS consecutive output rows, keeps the
+//     activation slice it needs in registers (the ROWS*K elements of a unit tile the input
+//     vector exactly ROWS times, so LayerNorm statistics are one DPP reduction / ROWS) --
+//     no LDS, no workgroup barrier in the K=model_dim kernels;
+//   * LayerNorm gain/bias are folded into the following matrix at load (W' = W diag(g),
+//     b' = b + W beta), so the prologue is only (x - mean) * rstd;
+//   * reductions are fixed-order DPP butterflies: results are bit-reproducible run to run.
 //
 // Reference arithmetic: indextts/gpt/transformers_gpt2.py:480-667 (block), :1164 (ln_f);
 // indextts/gpt/model_v2.py:53,156-160,185 (embed, final_norm+mel_head).
@@ -14,39 +22,30 @@
 
 namespace ixtts {
 
-constexpr int HD = 64;        // head dim (asserted at create)
-constexpr int NSPLIT_MAX = 16;
-constexpr int PART_STRIDE = 2 + HD;  // (m, l, acc[64]) per (b, head, split)
+constexpr int HD = 64;  // head dim (asserted at create)
 
-enum { IN_LN = 0, IN_LN2 = 1, IN_PLAIN = 2, IN_ATTN = 3 };
-enum { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3, EPI_STORE = 4 };
+enum { IN_LN = 0, IN_LN2 = 1, IN_PLAIN = 2 };
+enum { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3 };
 
 struct GemvArgs {
-  const void* wt;       // [N][K] weights (float or bf16), K contiguous
-  const float* bias;    // [N]
+  const void* wt;       // [N][K] weights (float or bf16), K contiguous; LN gain pre-folded
+  const float* bias;    // [N] (LN bias pre-folded)
   int N;
   int slot0;            // first sequence slot
-  // input
-  const float* xin;     // IN_LN/IN_LN2: h [slots][D]; IN_PLAIN: [slots][K]; IN_ATTN: partials
-  const float* ln_w;    // LN gain/bias (IN_LN, IN_LN2 first norm)
+  const float* xin;     // [slots][K]: residual stream h (IN_LN*), attention output / ff (IN_PLAIN)
+  const float* ln_w;    // IN_LN2 only: explicit gain/bias of the FIRST norm (ln_f)
   const float* ln_b;
-  const float* ln2_w;   // second norm (IN_LN2)
-  const float* ln2_b;
-  int nsplit;           // IN_ATTN
-  // output
   float* out;           // EPI_RESID: h (in place add); EPI_GELU: ff; EPI_LOGITS: logits; EPI_QKV: q
   int out_stride;       // floats between slots in `out`
-  void* kcache;         // EPI_QKV
+  void* kcache;         // EPI_QKV: layer base [slots][H][smax][64]
   void* vcache;
   const int* cur_len;   // [slots] KV position of the token being forwarded
-  int layer_stride;     // elements between layers handled by caller (pointer pre-offset); unused
   int smax;             // KV capacity per (slot, head)
   int heads;
-  float* norm_out;      // optional: IN_LN2 kernels store the normalised vector (latent rows) [slots][K]
+  float* norm_out;      // optional (IN_LN2): ln_f output BEFORE the folded final_norm gain, unused
 };
 
-// 16 bytes of weights per lane per load, kept RAW in registers until the dot product so
-// the loads stay in flight across the LayerNorm / attention-merge prologue.
+// 16 bytes of weights per lane per load, kept RAW in registers until the dot product.
 template <typename WT>
 struct WVec;
 template <>
@@ -65,8 +64,6 @@ struct WVec<bf16> {
   }
 };
 
-__device__ __forceinline__ float to_f32(float v) { return v; }
-__device__ __forceinline__ float to_f32(bf16 v) { return __bfloat162float(v); }
 __device__ __forceinline__ void store_kv(float* p, float v) { *p = v; }
 __device__ __forceinline__ void store_kv(bf16* p, float v) { *p = __float2bfloat16(v); }
 
@@ -76,113 +73,151 @@ __device__ __forceinline__ float gelu_new_f(float x) {
   return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
 }
 
-// block-wide sum over 256 threads (4 waves), result broadcast; fixed order
-__device__ __forceinline__ float block_sum_256(float v, float* red /*[4]*/) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-// LayerNorm of xs[0..K) in place (two-pass, eps 1e-5), all 256 threads participate.
-template <int K>
-__device__ __forceinline__ void layer_norm_lds(float* xs, const float* __restrict__ w, const float* __restrict__ b,
-                                               float* red) {
-  float s = 0.f;
-  for (int i = threadIdx.x; i < K; i += 256) s += xs[i];
-  const float mean = block_sum_256(s, red) * (1.0f / K);
-  float q = 0.f;
-  for (int i = threadIdx.x; i < K; i += 256) {
-    float d = xs[i] - mean;
-    q += d * d;
+// Shared epilogue: lane (r*B + b) owns output row r of the unit for slot b.
+template <int K, int ROWS, int B, int EPI, typename KVT>
+__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int lane, int unit, const float (&tot)[ROWS][B],
+                                              float pre_bias, float pre_res, int pre_pos) {
+  if (lane < ROWS * B) {
+    const int r = lane / B, b = lane % B;
+    float mine = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr)
+#pragma unroll
+      for (int bb = 0; bb < B; ++bb)
+        if (rr == r && bb == b) mine = tot[rr][bb];
+    const int n = unit * ROWS + r;
+    if (n < a.N) {
+      const int slot = a.slot0 + b;
+      const float v = mine + pre_bias;
+      if constexpr (EPI == EPI_RESID) {
+        a.out[(size_t)slot * a.out_stride + n] = pre_res + v;
+      } else if constexpr (EPI == EPI_GELU) {
+        a.out[(size_t)slot * a.out_stride + n] = gelu_new_f(v);
+      } else if constexpr (EPI == EPI_LOGITS) {
+        a.out[(size_t)slot * a.out_stride + n] = v;
+      } else {  // EPI_QKV: q -> buffer, k/v -> cache at position cur_len[slot]
+        constexpr int D = K;
+        if (n < D) {
+          a.out[(size_t)slot * a.out_stride + n] = v;
+        } else {
+          const int which = n / D;  // 1: k, 2: v
+          const int c = n - which * D;
+          const int hh = c / HD, d = c % HD;
+          KVT* cache = reinterpret_cast<KVT*>(which == 1 ? a.kcache : a.vcache);
+          store_kv(cache + (((size_t)slot * a.heads + hh) * a.smax + pre_pos) * HD + d, v);
+        }
+      }
+    }
   }
-  const float var = block_sum_256(q, red) * (1.0f / K);
-  const float rstd = 1.0f / sqrtf(var + 1e-5f);
-  for (int i = threadIdx.x; i < K; i += 256) xs[i] = (xs[i] - mean) * rstd * w[i] + b[i];
-  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------
-// GEMV: y[b][n] = sum_k x[b][k] * Wt[n][k] (+ bias) with fused prologue / epilogue.
-// One wave = UNITS units of ROWS consecutive weight rows (ROWS*K elements, contiguous in
-// HBM): the wave streams them as ROWS*K/(64*VEC) 16-byte loads per lane.
+// Register-resident GEMV (K = model_dim kernels: QKV, out-proj, FC, head).
 template <typename WT, int K, int ROWS, int UNITS, int B, int INP, int EPI, typename KVT>
-__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
+__global__ __launch_bounds__(256) void gemv_reg_kernel(GemvArgs a) {
   constexpr int VEC = WVec<WT>::VEC;
-  constexpr int PER = 64 * VEC;            // elements per wave-load
-  constexpr int NL = ROWS * K / PER;       // loads per lane per unit
+  constexpr int PER = 64 * VEC;       // elements per wave-load
+  constexpr int NL = ROWS * K / PER;  // loads per lane per unit
   static_assert(ROWS * K % PER == 0, "unit must be a whole number of wave loads");
   static_assert(K % VEC == 0, "row length must be a multiple of the vector width");
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [B][K]
-  __shared__ float red[4];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int unit0 = (blockIdx.x * 4 + wave) * UNITS;
   const int n_units = (a.N + ROWS - 1) / ROWS;
+  if (unit0 >= n_units) return;  // wave-uniform; no barriers in this kernel
 
-  // ---- issue the weight loads first: they do not depend on the prologue
+  // ---- 1. activation slice -> registers (L2-resident, issued first: vmcnt retires in order)
+  float xr[B][NL][VEC];
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const float* xs = a.xin + (size_t)(a.slot0 + b) * K;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int e = j * PER + lane * VEC;
+      const int k0 = e % K;
+#pragma unroll
+      for (int v4 = 0; v4 < VEC / 4; ++v4) {
+        const float4 t = *reinterpret_cast<const float4*>(xs + k0 + v4 * 4);
+        xr[b][j][v4 * 4 + 0] = t.x; xr[b][j][v4 * 4 + 1] = t.y; xr[b][j][v4 * 4 + 2] = t.z; xr[b][j][v4 * 4 + 3] = t.w;
+      }
+    }
+  }
+  // ---- 2. epilogue operands of the rows this lane will write
+  float pre_bias[UNITS], pre_res[UNITS];
+  int pre_pos = 0;
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u) {
+    pre_bias[u] = 0.f;
+    pre_res[u] = 0.f;
+    if (lane < ROWS * B) {
+      const int n = (unit0 + u) * ROWS + lane / B;
+      if (n < a.N) {
+        pre_bias[u] = a.bias[n];
+        if constexpr (EPI == EPI_RESID) pre_res[u] = a.out[(size_t)(a.slot0 + lane % B) * a.out_stride + n];
+      }
+    }
+  }
+  if constexpr (EPI == EPI_QKV) {
+    if (lane < ROWS * B) pre_pos = a.cur_len[a.slot0 + lane % B];
+  }
+  // ---- 3. weight stream (HBM)
   uint4 wraw[UNITS][NL];
 #pragma unroll
   for (int u = 0; u < UNITS; ++u) {
     const int unit = unit0 + u;
-    if (unit < n_units) {
-      const WT* base = reinterpret_cast<const WT*>(a.wt) + (size_t)unit * ROWS * K;
-      const int rows_here = min(ROWS, a.N - unit * ROWS);
+    const WT* base = reinterpret_cast<const WT*>(a.wt) + (size_t)unit * ROWS * K;
+    const int rows_here = (unit < n_units) ? min(ROWS, a.N - unit * ROWS) : 0;
 #pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        const int e = j * PER + lane * VEC;
-        if (e < rows_here * K) {
-          wraw[u][j] = *reinterpret_cast<const uint4*>(base + e);
-        } else {
-          wraw[u][j] = make_uint4(0u, 0u, 0u, 0u);
-        }
-      }
+    for (int j = 0; j < NL; ++j) {
+      const int e = j * PER + lane * VEC;
+      wraw[u][j] = (e < rows_here * K) ? *reinterpret_cast<const uint4*>(base + e) : make_uint4(0u, 0u, 0u, 0u);
     }
   }
-
-  // ---- prologue: build the activation vector(s) in LDS
+  // ---- 4. LayerNorm in registers (gain/bias of the norm feeding the matrix are pre-folded)
+  if constexpr (INP == IN_LN || INP == IN_LN2) {
+    constexpr int NPASS = (INP == IN_LN2) ? 2 : 1;
 #pragma unroll
-  for (int b = 0; b < B; ++b) {
-    float* x = xs + b * K;
-    const int slot = a.slot0 + b;
-    if constexpr (INP == IN_LN || INP == IN_LN2) {
-      const float* hsrc = a.xin + (size_t)slot * K;
-      for (int i = threadIdx.x; i < K; i += 256) x[i] = hsrc[i];
-      __syncthreads();
-      layer_norm_lds<K>(x, a.ln_w, a.ln_b, red);
-      if constexpr (INP == IN_LN2) {
-        layer_norm_lds<K>(x, a.ln2_w, a.ln2_b, red);
-        if (a.norm_out && blockIdx.x == 0)
-          for (int i = threadIdx.x; i < K; i += 256) a.norm_out[(size_t)slot * K + i] = x[i];
+    for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) s += xr[b][j][v];
+        const float mean = wave_sum(s) * (1.0f / (ROWS * K));
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float d = xr[b][j][v] - mean;
+            q = fmaf(d, d, q);
+          }
+        const float var = wave_sum(q) * (1.0f / (ROWS * K));
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) xr[b][j][v] = (xr[b][j][v] - mean) * rstd;
       }
-    } else if constexpr (INP == IN_PLAIN) {
-      const float* src = a.xin + (size_t)slot * K;
-      for (int i = threadIdx.x; i < K; i += 256) x[i] = src[i];
-    } else {  // IN_ATTN: combine the split-S partials of every head (flash-decode merge)
-      const int H = K / HD;
-      for (int e = threadIdx.x; e < K; e += 256) {
-        const int hh = e / HD, d = e % HD;
-        const float* p = a.xin + ((size_t)(slot * H + hh) * a.nsplit) * PART_STRIDE;
-        float M = -INFINITY;
-        for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, p[s * PART_STRIDE]);
-        float l = 0.f, o = 0.f;
-        for (int s = 0; s < a.nsplit; ++s) {
-          const float ms = p[s * PART_STRIDE];
-          if (ms > -INFINITY) {
-            const float sc = expf(ms - M);
-            l += p[s * PART_STRIDE + 1] * sc;
-            o += p[s * PART_STRIDE + 2 + d] * sc;
+      if (INP == IN_LN2 && pass == 0) {
+        // explicit affine of the first norm (ln_f); the second norm's affine is folded
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+          const int k0 = (j * PER + lane * VEC) % K;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float g = a.ln_w[k0 + v], bb = a.ln_b[k0 + v];
+#pragma unroll
+            for (int b = 0; b < B; ++b) xr[b][j][v] = fmaf(xr[b][j][v], g, bb);
           }
         }
-        x[e] = o / l;
       }
     }
   }
-  __syncthreads();
-
-  // ---- dot products
+  // ---- 5. dot products, DPP reduction, epilogue
 #pragma unroll
   for (int u = 0; u < UNITS; ++u) {
     const int unit = unit0 + u;
@@ -195,7 +230,98 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int e = j * PER + lane * VEC;
-      const int row = e / K;  // K is a compile-time constant
+      const int row = e / K;
+      float wv[VEC];
+      WVec<WT>::unpack(wraw[u][j], wv);
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        float d = 0.f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) d = fmaf(wv[v], xr[b][j][v], d);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) acc[r][b] += (row == r) ? d : 0.f;
+      }
+    }
+    float tot[ROWS][B];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int b = 0; b < B; ++b) tot[r][b] = wave_sum(acc[r][b]);
+    gemv_epilogue<K, ROWS, B, EPI, KVT>(a, lane, unit, tot, pre_bias[u], pre_res[u], pre_pos);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// LDS-staged GEMV for the long-K matrix (MLP out, K = 4*model_dim): the activation vector
+// (20 KB per slot) is shared by the workgroup's 4 waves through LDS; one barrier.
+template <typename WT, int K, int ROWS, int UNITS, int B, int EPI, typename KVT>
+__global__ __launch_bounds__(256) void gemv_lds_kernel(GemvArgs a) {
+  constexpr int VEC = WVec<WT>::VEC;
+  constexpr int PER = 64 * VEC;
+  constexpr int NL = ROWS * K / PER;
+  static_assert(ROWS * K % PER == 0, "unit must be a whole number of wave loads");
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [B][K]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int unit0 = (blockIdx.x * 4 + wave) * UNITS;
+  const int n_units = (a.N + ROWS - 1) / ROWS;
+
+  // activation vector: global -> registers (issued before the weight stream)
+  constexpr int TOT4 = B * K / 4;
+  constexpr int XV = (TOT4 + 255) / 256;  // float4 per thread
+  const float* xbase = a.xin + (size_t)a.slot0 * K;  // slots are contiguous: [slot0 .. slot0+B) x K
+  float4 xv[XV];
+#pragma unroll
+  for (int i = 0; i < XV; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    xv[i] = (TOT4 % 256 == 0 || idx < TOT4) ? *reinterpret_cast<const float4*>(xbase + (size_t)idx * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float pre_bias[UNITS], pre_res[UNITS];
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u) {
+    pre_bias[u] = 0.f;
+    pre_res[u] = 0.f;
+    if (lane < ROWS * B) {
+      const int n = (unit0 + u) * ROWS + lane / B;
+      if (n < a.N) {
+        pre_bias[u] = a.bias[n];
+        if constexpr (EPI == EPI_RESID) pre_res[u] = a.out[(size_t)(a.slot0 + lane % B) * a.out_stride + n];
+      }
+    }
+  }
+  uint4 wraw[UNITS][NL];
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u) {
+    const int unit = unit0 + u;
+    const WT* base = reinterpret_cast<const WT*>(a.wt) + (size_t)unit * ROWS * K;
+    const int rows_here = (unit < n_units) ? min(ROWS, a.N - unit * ROWS) : 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int e = j * PER + lane * VEC;
+      wraw[u][j] = (e < rows_here * K) ? *reinterpret_cast<const uint4*>(base + e) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < XV; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    if (TOT4 % 256 == 0 || idx < TOT4) *reinterpret_cast<float4*>(xs + idx * 4) = xv[i];
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u) {
+    const int unit = unit0 + u;
+    if (unit >= n_units) break;
+    float acc[ROWS][B];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int e = j * PER + lane * VEC;
+      const int row = e / K;
       const int k0 = e - row * K;
       float wv[VEC];
       WVec<WT>::unpack(wraw[u][j], wv);
@@ -205,65 +331,38 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         float d = 0.f;
 #pragma unroll
         for (int v4 = 0; v4 < VEC / 4; ++v4) {
-          const float4 xv = *reinterpret_cast<const float4*>(x + v4 * 4);
-          d = fmaf(wv[v4 * 4 + 0], xv.x, d);
-          d = fmaf(wv[v4 * 4 + 1], xv.y, d);
-          d = fmaf(wv[v4 * 4 + 2], xv.z, d);
-          d = fmaf(wv[v4 * 4 + 3], xv.w, d);
+          const float4 t = *reinterpret_cast<const float4*>(x + v4 * 4);
+          d = fmaf(wv[v4 * 4 + 0], t.x, d);
+          d = fmaf(wv[v4 * 4 + 1], t.y, d);
+          d = fmaf(wv[v4 * 4 + 2], t.z, d);
+          d = fmaf(wv[v4 * 4 + 3], t.w, d);
         }
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) acc[r][b] += (row == r) ? d : 0.f;
       }
     }
-    // ---- reduce + epilogue (lane 0 of the wave owns the unit's rows)
+    float tot[ROWS][B];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      const int n = unit * ROWS + r;
+    for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-      for (int b = 0; b < B; ++b) {
-        const float tot = wave_sum(acc[r][b]);
-        if (lane == 0 && n < a.N) {
-          const int slot = a.slot0 + b;
-          float v = tot + a.bias[n];
-          if constexpr (EPI == EPI_RESID) {
-            float* o = a.out + (size_t)slot * a.out_stride + n;
-            *o = *o + v;
-          } else if constexpr (EPI == EPI_GELU) {
-            a.out[(size_t)slot * a.out_stride + n] = gelu_new_f(v);
-          } else if constexpr (EPI == EPI_LOGITS || EPI == EPI_STORE) {
-            a.out[(size_t)slot * a.out_stride + n] = v;
-          } else {  // EPI_QKV: q -> buffer, k/v -> cache at position cur_len[slot]
-            constexpr int D = K;
-            if (n < D) {
-              a.out[(size_t)slot * a.out_stride + n] = v;
-            } else {
-              const int which = n / D;  // 1: k, 2: v
-              const int c = n - which * D;
-              const int hh = c / HD, d = c % HD;
-              const int pos = a.cur_len[slot];
-              KVT* cache = reinterpret_cast<KVT*>(which == 1 ? a.kcache : a.vcache);
-              store_kv(cache + (((size_t)slot * a.heads + hh) * a.smax + pos) * HD + d, v);
-            }
-          }
-        }
-      }
-    }
+      for (int b = 0; b < B; ++b) tot[r][b] = wave_sum(acc[r][b]);
+    gemv_epilogue<K, ROWS, B, EPI, KVT>(a, lane, unit, tot, pre_bias[u], pre_res[u], 0);
   }
 }
 
 // ------------------------------------------------------------------------------------
-// Split-S single-query attention (flash-decode): grid (H, nsplit, B), 256 threads.
-// lane -> (position lane>>2 of a 16-position group, 16-dim slice lane&3); each 4-lane
-// group keeps an online-softmax state over its positions; states are merged with
-// wavefront shuffles, then across the 4 waves through LDS.
+// Single-query attention: grid (H, B), NW*64 threads.  lane -> (position lane>>2 of a
+// 16-position group, 16-dim slice lane&3); each 4-lane group keeps an online-softmax state
+// over its positions; states merge with wavefront shuffles, then across waves through LDS.
+// Output is the normalised head vector (softmax(q k^T / 8) v), keys in [valid_from, cur_len].
 struct AttnArgs {
   const float* q;       // [slots][D]
   const void* kcache;   // layer base: [slots][H][smax][64]
   const void* vcache;
-  float* part;          // [slots][H][nsplit][PART_STRIDE]
-  const int* cur_len;   // position of the new token; keys [valid_from, cur_len]
+  float* out;           // [slots][D]
+  const int* cur_len;
   const int* valid_from;
-  int slot0, heads, smax, nsplit, D;
+  int slot0, heads, smax, D;
 };
 
 template <typename KVT>
@@ -286,24 +385,23 @@ __device__ __forceinline__ void load16<bf16>(const bf16* p, float (&o)[16]) {
   }
 }
 
-template <typename KVT>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
-  __shared__ float sm[4][4][2 + 16];  // [wave][dpart][m,l,acc16]
-  const int hh = blockIdx.x, split = blockIdx.y, slot = a.slot0 + blockIdx.z;
+template <typename KVT, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
+  __shared__ float sm[NW][4][2 + 16];  // [wave][dpart][m,l,acc16]
+  const int hh = blockIdx.x, slot = a.slot0 + blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pg = lane >> 2, dp = lane & 3;
-  const int S = a.cur_len[slot] + 1;
-  const int vf = a.valid_from[slot];
-  const int n = S - vf;
-  const int chunk = (n + a.nsplit - 1) / a.nsplit;
-  const int p_begin = vf + split * chunk;
-  const int p_end = min(S, p_begin + chunk);
+  const int p_end = a.cur_len[slot] + 1;
+  const int p_begin = a.valid_from[slot];
 
   float qv[16];
   {
     const float* qp = a.q + (size_t)slot * a.D + hh * HD + dp * 16;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) qv[i] = qp[i] * 0.125f;  // 1/sqrt(64)
+    for (int i = 0; i < 4; ++i) {
+      const float4 t = reinterpret_cast<const float4*>(qp)[i];
+      qv[4 * i] = t.x * 0.125f; qv[4 * i + 1] = t.y * 0.125f; qv[4 * i + 2] = t.z * 0.125f; qv[4 * i + 3] = t.w * 0.125f;  // 1/sqrt(64)
+    }
   }
   const KVT* kb = reinterpret_cast<const KVT*>(a.kcache) + ((size_t)slot * a.heads + hh) * a.smax * HD + dp * 16;
   const KVT* vb = reinterpret_cast<const KVT*>(a.vcache) + ((size_t)slot * a.heads + hh) * a.smax * HD + dp * 16;
@@ -312,7 +410,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  for (int p0 = p_begin + wave * 16; p0 < p_end; p0 += 64) {
+  for (int p0 = p_begin + wave * 16; p0 < p_end; p0 += NW * 16) {
     const int p = p0 + pg;
     const bool ok = p < p_end;
     float kv[16], vv[16];
@@ -359,14 +457,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   }
   __syncthreads();
   if (threadIdx.x < 64) {
-    // thread t -> output dim t: merge 4 waves in fixed order
     const int d = threadIdx.x, dpp = d >> 4, di = d & 15;
     float M = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) M = fmaxf(M, sm[w][dpp][0]);
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, sm[w][dpp][0]);
     float L = 0.f, O = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const float mw = sm[w][dpp][0];
       if (mw > -INFINITY) {
         const float sc = expf(mw - M);
@@ -374,12 +471,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
         O += sm[w][dpp][2 + di] * sc;
       }
     }
-    float* out = a.part + (((size_t)slot * a.heads + hh) * a.nsplit + split) * PART_STRIDE;
-    if (d == 0) {
-      out[0] = M;
-      out[1] = L;
-    }
-    out[2 + d] = O;
+    a.out[(size_t)slot * a.D + hh * HD + d] = O / L;
   }
 }
 
@@ -474,9 +566,9 @@ __global__ void set_row_kernel(float* h, const float* row, const float* add, int
   if (blockIdx.x == 0 && threadIdx.x == 0) cur_len[slot] = pos;
 }
 
-// ---- weight packing (device side): [K][N] fp32 -> Wt[N][K] in WT ; or plain convert
-template <typename WT>
-__global__ void pack_transpose_kernel(const float* __restrict__ src, WT* __restrict__ dst, int K, int N) {
+// ---- weight packing (device side)
+// [K][N] fp32 (HF Conv1D) -> staging Wt[N][K] fp32
+__global__ void pack_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int K, int N) {
   __shared__ float tile[32][33];
   const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   for (int i = threadIdx.y; i < 32; i += blockDim.y) {
@@ -486,17 +578,31 @@ __global__ void pack_transpose_kernel(const float* __restrict__ src, WT* __restr
   __syncthreads();
   for (int i = threadIdx.y; i < 32; i += blockDim.y) {
     int n = n0 + i, k = k0 + threadIdx.x;
-    if (n < N && k < K) {
-      if constexpr (sizeof(WT) == 4) dst[(size_t)n * K + k] = tile[threadIdx.x][i];
-      else dst[(size_t)n * K + k] = __float2bfloat16(tile[threadIdx.x][i]);
-    }
+    if (n < N && k < K) dst[(size_t)n * K + k] = tile[threadIdx.x][i];
   }
 }
+
+// finalize: dst[n][k] = WT(src[n][k] * g[k]) ; bias[n] += sum_k src[n][k] * beta[k]   (g/beta may be null)
+// one wave per output row.
 template <typename WT>
-__global__ void pack_convert_kernel(const float* __restrict__ src, WT* __restrict__ dst, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    if constexpr (sizeof(WT) == 4) dst[i] = src[i];
-    else dst[i] = __float2bfloat16(src[i]);
+__global__ __launch_bounds__(256) void fold_convert_kernel(const float* __restrict__ src, const float* __restrict__ g,
+                                                            const float* __restrict__ beta, float* __restrict__ bias,
+                                                            WT* __restrict__ dst, int N, int K) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const float* s = src + (size_t)n * K;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = s[k];
+    const float wf = g ? w * g[k] : w;
+    if (beta) acc = fmaf(w, beta[k], acc);
+    if constexpr (sizeof(WT) == 4) dst[(size_t)n * K + k] = wf;
+    else dst[(size_t)n * K + k] = __float2bfloat16(wf);
+  }
+  if (beta) {
+    acc = wave_sum(acc);
+    if (lane == 0) bias[n] += acc;
   }
 }
 
