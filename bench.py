@@ -1,0 +1,263 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the MI355X hot path on BASELINE.json's metric.
+
+Workload (configs[1], SURVEY.md 8(d) "Config 2"): ONE /tts request = 200-token zh text ->
+2 segments x 100 tokens (prompt P = 137 rows), 5 s speaker prompt already reduced to
+`conds_latent`; greedy fixed-length decode n = 1100 codes per segment (stop token
+suppressed: random weights never emit EOS), the latent GPT forward per segment, and
+BigVGAN over floor(1.72 n) = 1892 mel frames per segment -> 44.13 s of audio.
+The stages `north_star` leaves to PyTorch glue (conditioning encoders, s2mel CFM) are not
+built in this repo and are NOT in the timed region: their outputs (`conds_latent`, mel)
+are synthetic tensors resident in HBM, so `value` is the hot-path-only rate.
+
+One "step" = one such request.  Weak scaling: every rank serves its own request
+(process-per-GPU sharding, gunicorn_config.py:43-60); RCCL is used only to broadcast the
+packed weight arenas from rank 0 at load.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def host_cores():
+    """CPU share actually available to this process (cgroup quota / affinity), not the host's core count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("IXTTS_CPU_THREADS", "16"))))
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--tokens", type=int, default=100, help="text tokens per segment")
+    ap.add_argument("--codes", type=int, default=1100, help="mel codes per segment (11 per char)")
+    ap.add_argument("--segments", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    import voice_tts_amd.weights as WR
+    from voice_tts_amd.pipeline import HotPath, audio_seconds
+
+    D = WR.GPT_CFG["model_dim"]
+    n_seg, n_tok, n_codes = args.segments, args.tokens, args.codes
+    frames = int(n_codes * 1.72)
+    P = 34 + n_tok + 2 + 1
+    hp = HotPath(dtype=args.dtype, device=dev, max_batch=max(2, n_seg) if n_seg <= 4 else 4, max_seq=P + n_codes + 64,
+                 max_frames=frames)
+
+    # ---- load: rank 0 builds the (synthetic, seeded) weights, RCCL broadcasts the packed arenas
+    t_load = time.time()
+    Wg = Wb = None
+    if rank == 0:
+        Wg = WR.make_gpt_weights(WR.GPT_CFG, seed=1234)
+        Wb = WR.make_bigvgan_weights(WR.BIGVGAN_CFG, seed=1234)
+        hp.load(Wg, Wb)
+    if world > 1:
+        for t in hp.broadcast_tensors():
+            dist.broadcast(t, src=0)
+        if rank != 0:
+            hp.adopt()
+    torch.cuda.synchronize()
+    t_load = time.time() - t_load
+    log(f"weights loaded in {t_load:.1f}s")
+
+    # ---- synthetic request, resident in HBM before the timed region (seeded per rank)
+    g = torch.Generator().manual_seed(100 + rank)
+    conds = [(torch.randn(34, D, generator=g) * 0.5).to(dev) for _ in range(n_seg)]
+    texts = [torch.randint(2, 12000, (n_tok,), generator=g) for _ in range(n_seg)]
+    mels = [(torch.randn(1, 80, frames, generator=g) * 2 - 4).clamp(-11.5, 2).to(dev) for _ in range(n_seg)]
+    audio_s = audio_seconds([n_codes] * n_seg)
+
+    stage_ms = {"gpt_gen": 0.0, "gpt_forward": 0.0, "bigvgan": 0.0}
+
+    def request(timed):
+        def tick():
+            torch.cuda.synchronize()
+            return time.perf_counter()
+
+        t0 = tick()
+        prompts = [hp.prepare_gpt_inputs(conds[s], texts[s])[:2] for s in range(n_seg)]
+        codes = hp.generate(prompts, n_codes, repetition_penalty=10.0, fixed_length=True)
+        t1 = tick()
+        lats = [hp.latent(conds[s], texts[s], codes[s]) for s in range(n_seg)]
+        t2 = tick()
+        wavs = []
+        for s in range(n_seg):
+            w = hp.vocode(mels[s])
+            wavs.append(w.to(torch.int16).cpu())  # wav.cpu() per segment, int16 truncation (infer_v2.py:744,781)
+        t3 = tick()
+        if timed:
+            stage_ms["gpt_gen"] += (t1 - t0) * 1e3
+            stage_ms["gpt_forward"] += (t2 - t1) * 1e3
+            stage_ms["bigvgan"] += (t3 - t2) * 1e3
+        assert all(len(c) == n_codes for c in codes) and all(l.shape == (n_codes, D) for l in lats)
+        assert all(w.shape[-1] == frames * 256 for w in wavs)
+        return codes
+
+    for i in range(args.warmup):
+        request(False)
+        log(f"warmup {i} done")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        request(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    log(f"timed region: {elapsed:.2f}s for {args.steps} steps")
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * audio_s * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: the decode-step FC GEMV (largest weight stream per launch),
+    # timed live with events on the launch stream, cycling the 24 layers (314 MB bf16 > Infinity Cache)
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        B = n_seg if n_seg <= hp.gpt.max_batch else 1
+        es = 2 if args.dtype == "bf16" else 4
+        L = WR.GPT_CFG["layers"]
+        alg_bytes = 4 * D * D * es + 4 * D * 4 + B * D * 4 + B * 4 * D * 4
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for l in range(L):
+                hp.gpt.bench_gemv(2, l, B)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                for l in range(L):
+                    hp.gpt.bench_gemv(2, l, B)
+            gr.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 50
+            e0.record()
+            for _ in range(reps):
+                gr.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / (reps * L)
+        achieved = alg_bytes / (us * 1e-6) / 1e9
+        S_mid = P + n_codes // 2
+        step_bytes = hp.gpt.step_bytes(B, S_mid)
+        step_us = stage_ms["gpt_gen"] / args.steps * 1e3 / n_codes  # includes prefill + host syncs
+        roofline = {
+            "bound": "hbm", "kernel": f"gemv_reg_kernel<{args.dtype},K=1280,IN_LN,EPI_GELU> (decode LN2+FC, B={B})",
+            "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+            "traffic": None, "bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3),
+            "decode_step": {"alg_bytes": step_bytes, "us": round(step_us, 1), "achieved_GBps": round(step_bytes / step_us / 1e3, 1),
+                            "frac": round(step_bytes / step_us / 1e3 / 8000.0, 4), "kernels_per_step": 5 * L + 2},
+        }
+
+    # ---- CPU baseline: the oracle (port of the reference's CPU path) on a bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import gpt as OG
+        from oracle import vocoder as OV
+
+        torch.set_num_threads(host_cores())
+        cores = torch.get_num_threads()
+        log(f"cpu baseline on {cores} threads")
+        orc = OG.GptOracle(Wg, WR.GPT_CFG["layers"], WR.GPT_CFG["heads"])
+        fake, emb, mask = orc.prepare_gpt_inputs(conds[0].cpu(), texts[0])
+        tc = time.perf_counter()
+        logits, past = orc.prefill(emb, mask)
+        t_prefill = time.perf_counter() - tc
+        log(f"cpu prefill {t_prefill:.2f}s")
+        n_dec = 64
+        tc = time.perf_counter()
+        tok = 5
+        for k in range(1, n_dec + 1):
+            logits, past = orc.decode_step(tok, k, past, mask)
+            tok = int(torch.argmax(logits))
+        t_step = (time.perf_counter() - tc) / n_dec
+        log(f"cpu decode {t_step*1e3:.1f} ms/step")
+        n_lat = 600
+        tc = time.perf_counter()
+        orc.latent_pass(conds[0].cpu(), texts[0], torch.randint(0, 8192, (n_lat,)))
+        t_lat_row = (time.perf_counter() - tc) / (34 + n_tok + 2 + n_lat + 2)
+        log(f"cpu latent {t_lat_row*1e3:.2f} ms/row")
+        f_s = 256
+        tc = time.perf_counter()
+        OV.bigvgan_forward(mels[0][:, :, :f_s].cpu(), Wb)
+        t_frame = (time.perf_counter() - tc) / f_s
+        est = n_seg * (t_prefill + n_codes * t_step + (P + n_codes + 2) * t_lat_row + frames * t_frame)
+        cpu = {"value": round(audio_s / est, 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
+               "sample": f"oracle fp32: 1 prefill of {P} rows ({t_prefill:.2f}s), {n_dec} decode steps ({t_step*1e3:.1f} ms/step), "
+                         f"latent pass on {n_lat} codes ({t_lat_row*1e3:.2f} ms/row), BigVGAN {f_s} frames ({t_frame*1e3:.1f} ms/frame); "
+                         f"extrapolated linearly to the full request ({est:.0f}s est.)",
+               "rtf": round(est / audio_s, 3)}
+
+    if rank == 0:
+        out = {
+            "metric": "audio_seconds_per_second", "value": round(value, 3), "unit": "audio-s/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "rtf": round(elapsed / (audio_s * args.steps), 5),
+            "config": {
+                "workload": f"1 /tts request per GPU: {n_seg}x{n_tok}-token zh text segments (200-char utterance), greedy fixed-length "
+                            f"decode {n_codes} codes/segment batched B={n_seg}, latent GPT forward, BigVGAN {frames} frames/segment -> "
+                            f"{audio_s:.2f} s audio; conditioning encoders + s2mel not built: conds_latent/mel are synthetic HBM-resident inputs",
+                "segments": n_seg, "text_tokens_per_segment": n_tok, "codes_per_segment": n_codes, "mel_frames_per_segment": frames,
+                "audio_seconds_per_request": round(audio_s, 3), "parallelism": f"request-per-GPU x{world}, RCCL weight broadcast at load",
+                "gpt_precision": f"{args.dtype} weights+KV, fp32 accumulate", "bigvgan_precision": "fp32 (fp32 MFMA)",
+            },
+            "stage_ms_per_step": {k: round(v / args.steps, 2) for k, v in stage_ms.items()},
+            "load_s": round(t_load, 1),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

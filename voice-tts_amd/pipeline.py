@@ -1,0 +1,145 @@
+"""Host-side mirror of the hot loop of `IndexTTS2.infer_generator` (indextts/infer_v2.py:616-749)
+for the two stages this repo builds: the autoregressive GPT (`inference_speech` + latent
+`forward`) and the BigVGAN vocoder.  PyTorch is plumbing only (device tensors, the tiny
+embedding gathers of `prepare_gpt_inputs`); all heavy arithmetic runs in libixtts_hip.so.
+
+The stages between them that `north_star` leaves to PyTorch glue (conditioning encoders,
+s2mel length-regulator + CFM) are NOT part of this package; callers hand in
+`conds_latent` (model_v2.py:696) and the mel spectrogram (infer_v2.py:731).
+"""
+import numpy as np
+import torch
+
+from .bigvgan import BigVGAN
+from .gpt_engine import GptEngine
+from .weights import BIGVGAN_CFG, GPT_CFG
+
+SAMPLE_RATE = 22050  # infer_v2.py:607
+
+
+class _RawDeviceBuffer:
+    """Expose a raw device pointer to torch without copying (for the RCCL weight broadcast)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def arena_tensor(ptr, nbytes, device):
+    return torch.as_tensor(_RawDeviceBuffer(ptr, nbytes), device=device)
+
+
+class HotPath:
+    def __init__(self, gpt_cfg=None, bigvgan_cfg=None, dtype="bf16", device="cuda:0", max_batch=2, max_seq=2048,
+                 max_frames=2048, fast_sin=False):
+        self.device = torch.device(device)
+        self.gpt_cfg = dict(GPT_CFG if gpt_cfg is None else gpt_cfg)
+        self.bigvgan_cfg = dict(BIGVGAN_CFG if bigvgan_cfg is None else bigvgan_cfg)
+        self.gpt = GptEngine(self.gpt_cfg, dtype=dtype, max_seq=max_seq, max_batch=max_batch, device=self.device)
+        self.bigvgan = BigVGAN(self.bigvgan_cfg, max_frames=max_frames, fast_sin=fast_sin, device=self.device)
+        D = self.gpt_cfg["model_dim"]
+        # glue tables for prepare_gpt_inputs / the latent prefix (model_v2.py:380,388-390,402)
+        self.text_embedding = torch.zeros(self.gpt_cfg["number_text_tokens"] + 1, D, device=self.device)
+        self.text_pos_embedding = torch.zeros(self.gpt_cfg["max_text_tokens"] + 2, D, device=self.device)
+        self.speed_emb = torch.zeros(2, D, device=self.device)
+
+    # ------------------------------------------------------------------ weights
+    def load(self, gpt_sd, bigvgan_sd):
+        self.gpt.load_state_dict(gpt_sd)
+        self.bigvgan.load_state_dict(bigvgan_sd)
+        self.text_embedding.copy_(gpt_sd["text_embedding.weight"])
+        self.text_pos_embedding.copy_(gpt_sd["text_pos_embedding.emb.weight"])
+        self.speed_emb.copy_(gpt_sd["speed_emb.weight"])
+        return self
+
+    def broadcast_tensors(self):
+        """Device tensors that together hold every weight (rank 0 -> all, one call each)."""
+        gp, gn = self.gpt.arena()
+        bp, bn = self.bigvgan.arena()
+        return [arena_tensor(gp, gn, self.device), arena_tensor(bp, bn, self.device), self.text_embedding,
+                self.text_pos_embedding, self.speed_emb]
+
+    def adopt(self):
+        self.gpt.adopt_arena()
+        self.bigvgan.adopt_arena()
+        return self
+
+    # ------------------------------------------------------------------ G0
+    def prepare_gpt_inputs(self, conds_latent, text_ids):
+        """UnifiedVoice.prepare_gpt_inputs (model_v2.py:598-661), one sequence.
+
+        conds_latent [34, D] device; text_ids int [L].  Returns (embeds [P-1, D], n_left_pad, P).
+        """
+        c = self.gpt_cfg
+        t = torch.as_tensor(text_ids, dtype=torch.long, device=self.device).reshape(-1)
+        L = t.numel()
+        valid = (t != c["stop_text_token"]) & (t != c["start_text_token"])
+        t = t[valid]
+        t = torch.cat((t.new_tensor([c["start_text_token"]]), t, t.new_tensor([c["stop_text_token"]])))
+        temb = self.text_embedding[t] + self.text_pos_embedding[: t.numel()]
+        pad = L + 2 - t.numel()
+        parts = [conds_latent.to(self.device, torch.float32), temb]
+        if pad > 0:
+            parts.insert(0, torch.zeros(pad, temb.shape[1], device=self.device))
+        embeds = torch.cat(parts, 0)
+        return embeds, pad, embeds.shape[0] + 1
+
+    def conds_latent(self, cond32, emo_vec):
+        """inference_speech (model_v2.py:693-696)."""
+        c = cond32.to(self.device, torch.float32) + emo_vec.to(self.device, torch.float32).reshape(1, -1)
+        return torch.cat((c, self.speed_emb[1:2], self.speed_emb[0:1]), 0)
+
+    def latent_prefix(self, conds_latent, text_ids):
+        """[conds ; text_emb] rows of UnifiedVoice.forward (model_v2.py:579-589)."""
+        c = self.gpt_cfg
+        t = torch.as_tensor(text_ids, dtype=torch.long, device=self.device).reshape(-1)
+        t = torch.cat((t.new_tensor([c["start_text_token"]]), t, t.new_tensor([c["stop_text_token"]])))
+        temb = self.text_embedding[t] + self.text_pos_embedding[: t.numel()]
+        return torch.cat((conds_latent.to(self.device, torch.float32), temb), 0)
+
+    # ------------------------------------------------------------------ G1-G8
+    def generate(self, prompts, max_new, repetition_penalty=10.0, fixed_length=False, sync_every=64):
+        """Greedy decode of up to `max_batch` independent sequences together.
+
+        prompts: list of (embeds [P-1,D], n_left_pad).  Returns a list of int32 id arrays,
+        trimmed at the first stop token (inclusive), as `generate()` would return them.
+        """
+        B = len(prompts)
+        assert 1 <= B <= self.gpt.max_batch
+        for b, (emb, pad) in enumerate(prompts):
+            self.gpt.prefill(b, emb, pad)
+        done = 0
+        out = [None] * B
+        while done < max_new:
+            n = min(sync_every, max_new - done)
+            self.gpt.decode(B, n, repetition_penalty=repetition_penalty, suppress_stop=fixed_length)
+            done += n
+            fins = []
+            for b in range(B):
+                ids, fin = self.gpt.read(b)
+                out[b] = ids[:max_new]
+                fins.append(fin)
+            if all(fins):
+                break
+        return out
+
+    # ------------------------------------------------------------------ G9
+    def latent(self, conds_latent, text_ids, codes):
+        prefix = self.latent_prefix(conds_latent, text_ids)
+        codes = torch.as_tensor(np.asarray(codes), dtype=torch.int32, device=self.device)
+        return self.gpt.latent(prefix, codes)
+
+    # ------------------------------------------------------------------ V0-V5
+    def vocode(self, mel):
+        """bigvgan(mel.float()) then the PCM clamp of infer_v2.py:735-744: returns fp32 [1, T] scaled to +-32767."""
+        wav = self.bigvgan(mel.to(self.device, torch.float32)).squeeze(1)
+        return torch.clamp(32767 * wav, -32767.0, 32767.0)
+
+
+def audio_seconds(n_codes_per_segment, interval_silence_ms=200):
+    """Audio length the reference produces for these code counts (infer_v2.py:719,752-754)."""
+    total = 0.0
+    for n in n_codes_per_segment:
+        frames = int(n * 1.72)
+        total += frames * 256 / SAMPLE_RATE
+    total += (len(n_codes_per_segment) - 1) * interval_silence_ms / 1000.0
+    return total
