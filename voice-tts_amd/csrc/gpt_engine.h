@@ -1,0 +1,85 @@
+// gpt_engine.h -- engine state shared by gpt_engine.hip (decode, C ABI) and gpt_rows.hip (batched rows).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace ixtts {
+
+constexpr int MAXB = 4;
+
+enum TKind { T_VEC = 0, T_MAT_T = 1, T_MAT_N = 2, T_EMB = 3 };
+
+struct TDesc {
+  size_t off = 0;  // byte offset in the arena
+  int kind = T_VEC;
+  int64_t d0 = 0, d1 = 0;  // expected shape ([d0] or [d0][d1] as in the state dict)
+  size_t stage_off = 0;    // float offset in the fp32 staging arena (matrices only)
+  bool set = false;
+};
+
+struct LayerOff {
+  size_t ln1_w, ln1_b, wqkv, bqkv, wo, bo, ln2_w, ln2_b, wfc, bfc, wpr, bpr;
+};
+
+template <int D>
+struct Dims;
+template <>
+struct Dims<1280> {
+  static constexpr int R1 = 2, R4 = 1, U_QKV = 2, U_OUT = 1, U_FC = 2, U_PR = 1, U_HEAD = 4;
+};
+template <>
+struct Dims<128> {
+  static constexpr int R1 = 4, R4 = 1, U_QKV = 1, U_OUT = 1, U_FC = 1, U_PR = 1, U_HEAD = 1;
+};
+
+}  // namespace ixtts
+
+struct ixtts_gpt {
+  ixtts_gpt_cfg cfg;
+  int D, L, H, V, FF, slots, smax;
+  size_t esize;
+  uint8_t* arena = nullptr;
+  size_t arena_bytes = 0;
+  std::vector<ixtts::LayerOff> lo;
+  size_t lnf_w, lnf_b, fn_w, fn_b, whead, bhead, mel_emb, mel_pos;
+  std::map<std::string, ixtts::TDesc> tens;
+  bool finalized = false;
+  // state
+  float *h = nullptr, *q = nullptr, *ff = nullptr, *att = nullptr, *logits = nullptr, *rowbuf = nullptr;
+  float* stage = nullptr;  // fp32 [N][K] staging of every matrix until finalize folds/converts it
+  size_t stage_floats = 0;
+  void *kc = nullptr, *vc = nullptr;
+  int *cur_len = nullptr, *gen_count = nullptr, *prompt_len = nullptr, *valid_from = nullptr, *finished = nullptr,
+      *forced = nullptr;
+  int32_t* tokens = nullptr;
+  uint8_t* seen = nullptr;
+  ixtts_sampler_cfg* d_samp = nullptr;
+  ixtts_sampler_cfg samp_host;
+  float* scratch = nullptr;
+  size_t scratch_floats = 0;
+  hipStream_t cap_stream = nullptr;
+  hipGraphExec_t step_exec[ixtts::MAXB + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int host_prompt_len[ixtts::MAXB + 2];
+  int host_gen_est[ixtts::MAXB + 2];
+  // batched-rows workspace (prefill / latent): [max_seq][D] x4 + [max_seq][4D]
+  float *rx = nullptr, *rxn = nullptr, *rq = nullptr, *ratt = nullptr, *rff = nullptr;
+};
+
+#define A_F32(off) reinterpret_cast<float*>(h->arena + (off))
+#define A_PTR(off) reinterpret_cast<void*>(h->arena + (off))
+
+
+
+namespace ixtts {
+// Batched causal pass of T rows through the 24 layers for sequence slot `slot`:
+// rows X [T][D] (h->rx, in place) sit at cache positions pos0..pos0+T-1; keys < valid_from are masked.
+int forward_rows(ixtts_gpt* h, int slot, int T, int pos0, int valid_from, hipStream_t st);
+}  // namespace ixtts
+
+namespace ixtts {
+int final_norm_rows(ixtts_gpt* h, const float* x, float* y, int T, hipStream_t st);
+int embed_mel_rows(ixtts_gpt* h, float* x, const int32_t* codes, int rows, hipStream_t st);
+}  // namespace ixtts

@@ -14,75 +14,11 @@
 //   Matrices are stored TRANSPOSED (output row contiguous over K) in fp32 or bf16 so one
 //   wavefront streams whole rows with 16-byte-per-lane loads; vectors stay fp32.
 //   KV cache: [layer][slot][head][max_seq][64] (fp32 in parity mode, bf16 in throughput mode).
-#include <map>
-#include <vector>
-
+#define IXTTS_ENGINE_TU 1
+#include "gpt_engine.h"
 #include "gpt_kernels.h"
 
 using namespace ixtts;
-
-namespace {
-
-constexpr int MAXB = 4;
-
-enum TKind { T_VEC = 0, T_MAT_T = 1, T_MAT_N = 2, T_EMB = 3 };
-
-struct TDesc {
-  size_t off = 0;  // byte offset in the arena
-  int kind = T_VEC;
-  int64_t d0 = 0, d1 = 0;  // expected shape ([d0] or [d0][d1] as in the state dict)
-  size_t stage_off = 0;    // float offset in the fp32 staging arena (matrices only)
-  bool set = false;
-};
-
-struct LayerOff {
-  size_t ln1_w, ln1_b, wqkv, bqkv, wo, bo, ln2_w, ln2_b, wfc, bfc, wpr, bpr;
-};
-
-template <int D>
-struct Dims;
-template <>
-struct Dims<1280> {
-  static constexpr int R1 = 2, R4 = 1, U_QKV = 2, U_OUT = 1, U_FC = 2, U_PR = 1, U_HEAD = 4;
-};
-template <>
-struct Dims<128> {
-  static constexpr int R1 = 4, R4 = 1, U_QKV = 1, U_OUT = 1, U_FC = 1, U_PR = 1, U_HEAD = 1;
-};
-
-}  // namespace
-
-struct ixtts_gpt {
-  ixtts_gpt_cfg cfg;
-  int D, L, H, V, FF, slots, smax;
-  size_t esize;
-  uint8_t* arena = nullptr;
-  size_t arena_bytes = 0;
-  std::vector<LayerOff> lo;
-  size_t lnf_w, lnf_b, fn_w, fn_b, whead, bhead, mel_emb, mel_pos;
-  std::map<std::string, TDesc> tens;
-  bool finalized = false;
-  // state
-  float *h = nullptr, *q = nullptr, *ff = nullptr, *att = nullptr, *logits = nullptr, *rowbuf = nullptr;
-  float* stage = nullptr;  // fp32 [N][K] staging of every matrix until finalize folds/converts it
-  size_t stage_floats = 0;
-  void *kc = nullptr, *vc = nullptr;
-  int *cur_len = nullptr, *gen_count = nullptr, *prompt_len = nullptr, *valid_from = nullptr, *finished = nullptr,
-      *forced = nullptr;
-  int32_t* tokens = nullptr;
-  uint8_t* seen = nullptr;
-  ixtts_sampler_cfg* d_samp = nullptr;
-  ixtts_sampler_cfg samp_host;
-  float* scratch = nullptr;
-  size_t scratch_floats = 0;
-  hipStream_t cap_stream = nullptr;
-  hipGraphExec_t step_exec[MAXB + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  int host_prompt_len[MAXB + 2];
-  int host_gen_est[MAXB + 2];
-};
-
-#define A_F32(off) reinterpret_cast<float*>(h->arena + (off))
-#define A_PTR(off) reinterpret_cast<void*>(h->arena + (off))
 
 // ------------------------------------------------------------------------------------ launch helpers
 template <typename WT, typename KVT, int K, int ROWS, int UNITS, int B, int INP, int EPI>
@@ -368,6 +304,11 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   ok &= hipMalloc(&h->att, (size_t)S * D * 4) == hipSuccess;
   ok &= hipMalloc(&h->logits, (size_t)S * V * 4) == hipSuccess;
   ok &= hipMalloc(&h->rowbuf, (size_t)D * 4) == hipSuccess;
+  ok &= hipMalloc(&h->rx, (size_t)h->smax * D * 4) == hipSuccess;
+  ok &= hipMalloc(&h->rxn, (size_t)h->smax * D * 4) == hipSuccess;
+  ok &= hipMalloc(&h->rq, (size_t)h->smax * D * 4) == hipSuccess;
+  ok &= hipMalloc(&h->ratt, (size_t)h->smax * D * 4) == hipSuccess;
+  ok &= hipMalloc(&h->rff, (size_t)h->smax * FF * 4) == hipSuccess;
   ok &= hipMalloc(&h->cur_len, S * 4) == hipSuccess;
   ok &= hipMalloc(&h->gen_count, S * 4) == hipSuccess;
   ok &= hipMalloc(&h->prompt_len, S * 4) == hipSuccess;
@@ -506,6 +447,11 @@ extern "C" int ixtts_gpt_adopt_arena(ixtts_gpt* h) {
   } while (0)
 
 // ------------------------------------------------------------------------------------ prefill
+namespace ixtts {
+__global__ void add_vec_kernel(float* dst, const float* a, const float* b, int D) {
+  for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < D; i += blockDim.x * gridDim.x) dst[i] = a[i] + b[i];
+}
+}  // namespace ixtts
 extern "C" int ixtts_gpt_prefill(ixtts_gpt* h, int b, const float* embeds, int n_rows, int n_left_pad, void* stream) {
   NEED_READY(h, "gpt_prefill");
   IX_ARG(b >= 0 && b < h->cfg.max_batch, "gpt_prefill: slot %d out of range", b);
@@ -525,17 +471,15 @@ extern "C" int ixtts_gpt_prefill(ixtts_gpt* h, int b, const float* embeds, int n
   IX_HIP(hipMemcpyAsync(h->valid_from + b, &n_left_pad, 4, hipMemcpyHostToDevice, st));
   h->host_prompt_len[b] = P;
   h->host_gen_est[b] = 0;
-  // Row-by-row causal pass through the decode kernels (left-pad rows are never attended
-  // to -- valid_from masks them as keys -- so they are skipped outright).
-  for (int r = n_left_pad; r < P; ++r) {
-    if (r < n_rows) {
-      hipLaunchKernelGGL(set_row_kernel, dim3(4), dim3(256), 0, st, h->h, embeds + (size_t)r * D, (const float*)nullptr, D, b, h->cur_len, r);
-    } else {  // start_mel_token row: mel_embedding[start] + mel_pos_embedding[0]
-      hipLaunchKernelGGL(set_row_kernel, dim3(4), dim3(256), 0, st, h->h, A_F32(h->mel_emb) + (size_t)h->cfg.start_mel_token * D,
-                         (const float*)A_F32(h->mel_pos), D, b, h->cur_len, r);
-    }
-    IX_TRY(do_forward_layers(h, 1, b, st));
-  }
+  // Batched causal pass over the un-padded rows (left-pad rows are never attended to --
+  // valid_from masks them as keys -- so they are skipped outright).
+  const int T = P - n_left_pad;
+  IX_HIP(hipMemcpyAsync(h->rx, embeds + (size_t)n_left_pad * D, (size_t)(n_rows - n_left_pad) * D * 4, hipMemcpyDeviceToDevice, st));
+  // start_mel_token row: mel_embedding[start] + mel_pos_embedding[0]   (model_v2.py:146-148)
+  hipLaunchKernelGGL(add_vec_kernel, dim3(4), dim3(256), 0, st, h->rx + (size_t)(T - 1) * D,
+                     (const float*)(A_F32(h->mel_emb) + (size_t)h->cfg.start_mel_token * D), (const float*)A_F32(h->mel_pos), D);
+  IX_TRY(forward_rows(h, b, T, n_left_pad, n_left_pad, st));
+  IX_HIP(hipMemcpyAsync(h->h + (size_t)b * D, h->rx + (size_t)(T - 1) * D, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
   IX_TRY(do_head(h, 1, b, nullptr, st));
   IX_HIP(hipGetLastError());
   return IXTTS_OK;
@@ -622,53 +566,6 @@ extern "C" int ixtts_gpt_force_next(ixtts_gpt* h, int b, int32_t token, void* st
 }
 
 // ------------------------------------------------------------------------------------ latent pass
-namespace ixtts {
-__global__ void embed_code_row_kernel(float* h, const float* mel_emb, const float* mel_pos, const int32_t* codes, int idx,
-                                      int fixed_tok, int pos, int D, int slot, int* cur_len, int kvpos) {
-  const int tok = (fixed_tok >= 0) ? fixed_tok : codes[idx];
-  for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < D; i += blockDim.x * gridDim.x)
-    h[(size_t)slot * D + i] = mel_emb[(size_t)tok * D + i] + mel_pos[(size_t)pos * D + i];
-  if (blockIdx.x == 0 && threadIdx.x == 0) cur_len[slot] = kvpos;
-}
-
-__device__ __forceinline__ float block_sum_256(float v, float* red /*[4]*/) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-// LayerNorm of xs[0..K) in place (two-pass, eps 1e-5), all 256 threads participate.
-template <int K>
-__device__ __forceinline__ void layer_norm_lds(float* xs, const float* __restrict__ w, const float* __restrict__ b, float* red) {
-  float s = 0.f;
-  for (int i = threadIdx.x; i < K; i += 256) s += xs[i];
-  const float mean = block_sum_256(s, red) * (1.0f / K);
-  float q = 0.f;
-  for (int i = threadIdx.x; i < K; i += 256) {
-    const float d = xs[i] - mean;
-    q += d * d;
-  }
-  const float var = block_sum_256(q, red) * (1.0f / K);
-  const float rstd = 1.0f / sqrtf(var + 1e-5f);
-  for (int i = threadIdx.x; i < K; i += 256) xs[i] = (xs[i] - mean) * rstd * w[i] + b[i];
-  __syncthreads();
-}
-
-template <int K>
-__global__ __launch_bounds__(256) void final_norm_row_kernel(const float* h, const float* w1, const float* b1, const float* w2,
-                                                              const float* b2, float* out) {
-  __shared__ float xs[K];
-  __shared__ float red[4];
-  for (int i = threadIdx.x; i < K; i += 256) xs[i] = h[i];
-  __syncthreads();
-  layer_norm_lds<K>(xs, w1, b1, red);
-  layer_norm_lds<K>(xs, w2, b2, red);
-  for (int i = threadIdx.x; i < K; i += 256) out[i] = xs[i];
-}
-}  // namespace ixtts
-
 extern "C" int ixtts_gpt_latent(ixtts_gpt* h, const float* prefix, int n_prefix, const int32_t* codes, int n, float* latent,
                                 void* stream) {
   NEED_READY(h, "gpt_latent");
@@ -679,31 +576,13 @@ extern "C" int ixtts_gpt_latent(ixtts_gpt* h, const float* prefix, int n_prefix,
   hipStream_t st = (hipStream_t)stream;
   const int D = h->D;
   const int slot = h->slots - 1;  // scratch sequence
-  const int zero = 0;
-  IX_HIP(hipMemcpyAsync(h->valid_from + slot, &zero, 4, hipMemcpyHostToDevice, st));
-  const int total = n_prefix + n + 2;
   // Only the first n mel rows are returned ([:-2], model_v2.py:596) and the pass is causal,
   // so the two trailing rows (last code, stop) need not be computed at all.
   const int rows = n_prefix + n;
-  (void)total;
-  for (int r = 0; r < rows; ++r) {
-    if (r < n_prefix) {
-      hipLaunchKernelGGL(set_row_kernel, dim3(4), dim3(256), 0, st, h->h, prefix + (size_t)r * D, (const float*)nullptr, D, slot, h->cur_len, r);
-    } else {
-      const int mi = r - n_prefix;  // mel row index: 0 -> start token, i -> codes[i-1]
-      hipLaunchKernelGGL(embed_code_row_kernel, dim3(4), dim3(256), 0, st, h->h, (const float*)A_F32(h->mel_emb), (const float*)A_F32(h->mel_pos), codes,
-                         mi - 1, mi == 0 ? h->cfg.start_mel_token : -1, mi, D, slot, h->cur_len, r);
-    }
-    IX_TRY(do_forward_layers(h, 1, slot, st));
-    if (r >= n_prefix) {
-      float* dst = latent + (size_t)(r - n_prefix) * D;
-      const float* src = h->h + (size_t)slot * D;
-      if (D == 1280)
-        hipLaunchKernelGGL(final_norm_row_kernel<1280>, dim3(1), dim3(256), 0, st, src, (const float*)A_F32(h->lnf_w), (const float*)A_F32(h->lnf_b), (const float*)A_F32(h->fn_w), (const float*)A_F32(h->fn_b), dst);
-      else
-        hipLaunchKernelGGL(final_norm_row_kernel<128>, dim3(1), dim3(256), 0, st, src, (const float*)A_F32(h->lnf_w), (const float*)A_F32(h->lnf_b), (const float*)A_F32(h->fn_w), (const float*)A_F32(h->fn_b), dst);
-    }
-  }
+  IX_HIP(hipMemcpyAsync(h->rx, prefix, (size_t)n_prefix * D * 4, hipMemcpyDeviceToDevice, st));
+  IX_TRY(embed_mel_rows(h, h->rx + (size_t)n_prefix * D, codes, n, st));  // [start, codes[0..n-2]] at mel positions 0..n-1
+  IX_TRY(forward_rows(h, slot, rows, 0, 0, st));
+  IX_TRY(final_norm_rows(h, h->rx + (size_t)n_prefix * D, latent, n, st));
   IX_HIP(hipGetLastError());
   return IXTTS_OK;
 }
@@ -732,7 +611,8 @@ extern "C" int ixtts_gpt_destroy(ixtts_gpt* h) {
     if (h->step_exec[b]) hipGraphExecDestroy(h->step_exec[b]);
   if (h->cap_stream) hipStreamDestroy(h->cap_stream);
   void* ptrs[] = {h->arena, h->stage, h->kc, h->vc, h->h, h->q, h->ff, h->att, h->logits, h->rowbuf, h->cur_len, h->gen_count,
-                  h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->scratch};
+                  h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->scratch,
+                  h->rx, h->rxn, h->rq, h->ratt, h->rff};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete h;

@@ -475,6 +475,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
   }
 }
 
+#ifdef IXTTS_ENGINE_TU  // non-template kernels: compiled into gpt_engine.hip only
 // ------------------------------------------------------------------------------------
 // Sampler + embed (rows G8, G1).  One workgroup of 1024 threads per slot.
 struct SamplerState {
@@ -581,6 +582,8 @@ __global__ void pack_transpose_kernel(const float* __restrict__ src, float* __re
     if (n < N && k < K) dst[(size_t)n * K + k] = tile[threadIdx.x][i];
   }
 }
+
+#endif  // IXTTS_ENGINE_TU
 
 // finalize: dst[n][k] = WT(src[n][k] * g[k]) ; bias[n] += sum_k src[n][k] * beta[k]   (g/beta may be null)
 // one wave per output row.

@@ -1,0 +1,391 @@
+// gpt_rows.hip -- batched ("rows") causal pass of the GPT-2 trunk on gfx950: prefill of the
+// prompt (row G1, model_v2.py:144-155) and the latent forward (row G9, model_v2.py:554-596).
+//
+// T rows go through the 24 layers together: LayerNorm rows -> MFMA GEMM against the same
+// transposed/folded weight arena the decode GEMVs stream (QKV with KV-cache scatter, out-proj
+// + residual, FC + gelu_new, MLP-out + residual) and a causal row-attention that reads the
+// cache.  fp32 mode uses v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains, parity mode), bf16
+// mode converts the activation tile to bf16 in the LDS staging pass and uses
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+//
+// Reference arithmetic: indextts/gpt/transformers_gpt2.py:480-667.
+#include "gpt_engine.h"
+#include "gpt_kernels.h"
+
+namespace ixtts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// two fp32 -> packed bf16 pair (round-to-nearest-even, the plain cast lowers to v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned int pack_bf16x2(float a, float b) {
+  const unsigned short lo = __builtin_bit_cast(unsigned short, (__bf16)a);
+  const unsigned short hi = __builtin_bit_cast(unsigned short, (__bf16)b);
+  return (unsigned int)lo | ((unsigned int)hi << 16);
+}
+
+// ---- (x - mean) * rstd per row (gain/bias are folded into the next matrix); one wave per row
+template <int K>
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int T) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= T) return;
+  constexpr int PL = K / 64;  // elements per lane (20 for 1280, 2 for 128)
+  const float* xr = x + (size_t)row * K;
+  float v[PL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    v[i] = xr[lane + 64 * i];
+    s += v[i];
+  }
+  const float mean = wave_sum(s) * (1.0f / K);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    const float d = v[i] - mean;
+    q = fmaf(d, d, q);
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / K) + 1e-5f);
+  float* yr = y + (size_t)row * K;
+#pragma unroll
+  for (int i = 0; i < PL; ++i) yr[lane + 64 * i] = (v[i] - mean) * rstd;
+}
+
+// ---- ln_f (explicit affine) then final_norm (explicit affine) per row -> latent rows
+template <int K>
+__global__ __launch_bounds__(256) void final_norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int T,
+                                                               const float* __restrict__ w1, const float* __restrict__ b1,
+                                                               const float* __restrict__ w2, const float* __restrict__ b2) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= T) return;
+  constexpr int PL = K / 64;
+  const float* xr = x + (size_t)row * K;
+  float v[PL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) v[i] = xr[lane + 64 * i];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const float* w = pass == 0 ? w1 : w2;
+    const float* b = pass == 0 ? b1 : b2;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PL; ++i) s += v[i];
+    const float mean = wave_sum(s) * (1.0f / K);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      const float d = v[i] - mean;
+      q = fmaf(d, d, q);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / K) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < PL; ++i) v[i] = (v[i] - mean) * rstd * w[lane + 64 * i] + b[lane + 64 * i];
+  }
+  float* yr = y + (size_t)row * K;
+#pragma unroll
+  for (int i = 0; i < PL; ++i) yr[lane + 64 * i] = v[i];
+}
+
+// ---- GEMM: C[T][N] = A[T][K] . Wt[N][K]^T + bias, tile 64 x 128 x 32, 4 waves (2 x 2), wave tile 32 x 64
+enum { RE_QKV = 0, RE_RESID = 1, RE_GELU = 2 };
+
+struct GemmArgs {
+  const float* A;    // [T][K] fp32
+  const void* wt;    // [N][K]
+  const float* bias; // [N]
+  float* out;        // RE_QKV: q [T][D]; RE_RESID: x [T][N] (+=); RE_GELU: ff [T][N]
+  void* kcache;      // RE_QKV: slot+layer base [H][smax][64]
+  void* vcache;
+  int T, N, K, pos0, smax, D;
+};
+
+constexpr int GBM = 64, GBN = 128, GBK = 32;
+
+template <typename WT, int EPI, typename KVT>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
+  constexpr bool F32 = sizeof(WT) == 4;
+  // LDS tiles; bf16 tiles are stored as 16-bit with an 8-element pad, fp32 with a 1-float pad
+  constexpr int APITCH = F32 ? (GBK + 1) : (GBK + 8) / 2;  // in floats (bf16: 20 floats = 40 bf16)
+  constexpr int WPITCH = APITCH;
+  __shared__ __attribute__((aligned(16))) float As[GBM * APITCH];
+  __shared__ __attribute__((aligned(16))) float Ws[GBN * WPITCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  for (int k0 = 0; k0 < g.K; k0 += GBK) {
+    __syncthreads();
+    // ---- stage A tile [64][32] fp32 (2 float4 per thread)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx >> 3, c4 = idx & 7;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + row < g.T) v = *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + row) * g.K + k0 + c4 * 4);
+      if constexpr (F32) {
+        float* d = As + row * APITCH + c4 * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      } else {
+        uint2 pk;
+        pk.x = pack_bf16x2(v.x, v.y);
+        pk.y = pack_bf16x2(v.z, v.w);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(As) + row * (APITCH * 2) + c4 * 4) = pk;
+      }
+    }
+    // ---- stage W tile [128][32]
+    if constexpr (F32) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx >> 3, c4 = idx & 7;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + row < g.N) v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.wt) + (size_t)(n0 + row) * g.K + k0 + c4 * 4);
+        float* d = Ws + row * WPITCH + c4 * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx >> 2, c8 = idx & 3;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (n0 + row < g.N) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(g.wt) + (size_t)(n0 + row) * g.K + k0 + c8 * 8);
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(Ws) + row * (WPITCH * 2) + c8 * 8) = v;
+      }
+    }
+    __syncthreads();
+    if constexpr (F32) {
+#pragma unroll
+      for (int kk = 0; kk < GBK; kk += 2) {
+        const float a = As[(wm * 32 + l31) * APITCH + kk + lh];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float b = Ws[(wn * 64 + j * 32 + l31) * WPITCH + kk + lh];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+        }
+      }
+    } else {
+      const unsigned short* A16 = reinterpret_cast<const unsigned short*>(As);
+      const unsigned short* W16 = reinterpret_cast<const unsigned short*>(Ws);
+#pragma unroll
+      for (int kk = 0; kk < GBK; kk += 16) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(A16 + (wm * 32 + l31) * (APITCH * 2) + kk + lh * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(W16 + (wn * 64 + j * 32 + l31) * (WPITCH * 2) + kk + lh * 8);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- epilogue (C layout: col = lane&31 -> n, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> m)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + l31;
+    if (n >= g.N) continue;
+    const float bias = g.bias[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= g.T) continue;
+      const float v = acc[j][r] + bias;
+      if constexpr (EPI == RE_RESID) {
+        float* o = g.out + (size_t)m * g.N + n;
+        *o = *o + v;
+      } else if constexpr (EPI == RE_GELU) {
+        g.out[(size_t)m * g.N + n] = gelu_new_f(v);
+      } else {
+        if (n < g.D) {
+          g.out[(size_t)m * g.D + n] = v;
+        } else {
+          const int which = n / g.D;
+          const int c = n - which * g.D;
+          const int hh = c / HD, d = c % HD;
+          KVT* cache = reinterpret_cast<KVT*>(which == 1 ? g.kcache : g.vcache);
+          store_kv(cache + ((size_t)hh * g.smax + g.pos0 + m) * HD + d, v);
+        }
+      }
+    }
+  }
+}
+
+// ---- causal attention over rows: grid (H, T); row t attends keys [valid_from, pos0 + t]
+struct AttnRowsArgs {
+  const float* q;      // [T][D]
+  const void* kcache;  // slot+layer base [H][smax][64]
+  const void* vcache;
+  float* out;          // [T][D]
+  int T, D, smax, pos0, valid_from;
+};
+
+template <typename KVT>
+__global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsArgs a) {
+  constexpr int NW = 4;
+  __shared__ float sm[NW][4][2 + 16];
+  const int hh = blockIdx.x, row = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pg = lane >> 2, dp = lane & 3;
+  const int p_end = a.pos0 + row + 1;
+  const int p_begin = a.valid_from;
+  float qv[16];
+  {
+    const float* qp = a.q + (size_t)row * a.D + hh * HD + dp * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 t = reinterpret_cast<const float4*>(qp)[i];
+      qv[4 * i] = t.x * 0.125f; qv[4 * i + 1] = t.y * 0.125f; qv[4 * i + 2] = t.z * 0.125f; qv[4 * i + 3] = t.w * 0.125f;
+    }
+  }
+  const KVT* kb = reinterpret_cast<const KVT*>(a.kcache) + (size_t)hh * a.smax * HD + dp * 16;
+  const KVT* vb = reinterpret_cast<const KVT*>(a.vcache) + (size_t)hh * a.smax * HD + dp * 16;
+  float m = -INFINITY, l = 0.f, acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int p0 = p_begin + wave * 16; p0 < p_end; p0 += NW * 16) {
+    const int p = p0 + pg;
+    const bool ok = p < p_end;
+    float kv[16], vv[16];
+    float s = 0.f;
+    if (ok) {
+      load16<KVT>(kb + (size_t)p * HD, kv);
+      load16<KVT>(vb + (size_t)p * HD, vv);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s = fmaf(qv[i], kv[i], s);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (ok) {
+      const float mn = fmaxf(m, s);
+      const float sc = expf(m - mn);
+      const float pw = expf(s - mn);
+      l = l * sc + pw;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = fmaf(acc[i], sc, pw * vv[i]);
+      m = mn;
+    }
+  }
+#pragma unroll
+  for (int o = 4; o <= 32; o <<= 1) {
+    const float m2 = __shfl_xor(m, o, 64);
+    const float l2 = __shfl_xor(l, o, 64);
+    const float mn = fmaxf(m, m2);
+    const float s1 = (m > -INFINITY) ? expf(m - mn) : 0.f;
+    const float s2 = (m2 > -INFINITY) ? expf(m2 - mn) : 0.f;
+    l = l * s1 + l2 * s2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float a2 = __shfl_xor(acc[i], o, 64);
+      acc[i] = acc[i] * s1 + a2 * s2;
+    }
+    m = mn;
+  }
+  if (pg == 0) {
+    sm[wave][dp][0] = m;
+    sm[wave][dp][1] = l;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sm[wave][dp][2 + i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int d = threadIdx.x, dpp = d >> 4, di = d & 15;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, sm[w][dpp][0]);
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float mw = sm[w][dpp][0];
+      if (mw > -INFINITY) {
+        const float sc = expf(mw - M);
+        L += sm[w][dpp][1] * sc;
+        O += sm[w][dpp][2 + di] * sc;
+      }
+    }
+    a.out[(size_t)row * a.D + hh * HD + d] = O / L;
+  }
+}
+
+template <typename WT, typename KVT, int EPI>
+static void launch_gemm(const GemmArgs& g, hipStream_t st) {
+  dim3 grid(ceil_div(g.N, GBN), ceil_div(g.T, GBM));
+  hipLaunchKernelGGL((gemm_rows_kernel<WT, EPI, KVT>), grid, dim3(256), 0, st, g);
+}
+
+template <typename WT, typename KVT, int D>
+static int forward_rows_t(ixtts_gpt* h, int slot, int T, int pos0, int valid_from, hipStream_t st) {
+  const size_t lstride = (size_t)h->slots * D * h->smax * sizeof(KVT);
+  const size_t sstride = (size_t)D * h->smax * sizeof(KVT);
+  for (int l = 0; l < h->L; ++l) {
+    const LayerOff& o = h->lo[l];
+    uint8_t* kc = (uint8_t*)h->kc + l * lstride + slot * sstride;
+    uint8_t* vc = (uint8_t*)h->vc + l * lstride + slot * sstride;
+    hipLaunchKernelGGL(ln_rows_kernel<D>, dim3(ceil_div(T, 4)), dim3(256), 0, st, h->rx, h->rxn, T);
+    GemmArgs g;
+    g.A = h->rxn; g.wt = A_PTR(o.wqkv); g.bias = A_F32(o.bqkv); g.out = h->rq; g.kcache = kc; g.vcache = vc;
+    g.T = T; g.N = 3 * D; g.K = D; g.pos0 = pos0; g.smax = h->smax; g.D = D;
+    launch_gemm<WT, KVT, RE_QKV>(g, st);
+    AttnRowsArgs a;
+    a.q = h->rq; a.kcache = kc; a.vcache = vc; a.out = h->ratt; a.T = T; a.D = D; a.smax = h->smax; a.pos0 = pos0; a.valid_from = valid_from;
+    hipLaunchKernelGGL(attn_rows_kernel<KVT>, dim3(h->H, T), dim3(256), 0, st, a);
+    g.A = h->ratt; g.wt = A_PTR(o.wo); g.bias = A_F32(o.bo); g.out = h->rx; g.N = D; g.K = D;
+    launch_gemm<WT, KVT, RE_RESID>(g, st);
+    hipLaunchKernelGGL(ln_rows_kernel<D>, dim3(ceil_div(T, 4)), dim3(256), 0, st, h->rx, h->rxn, T);
+    g.A = h->rxn; g.wt = A_PTR(o.wfc); g.bias = A_F32(o.bfc); g.out = h->rff; g.N = 4 * D; g.K = D;
+    launch_gemm<WT, KVT, RE_GELU>(g, st);
+    g.A = h->rff; g.wt = A_PTR(o.wpr); g.bias = A_F32(o.bpr); g.out = h->rx; g.N = D; g.K = 4 * D;
+    launch_gemm<WT, KVT, RE_RESID>(g, st);
+  }
+  IX_HIP(hipGetLastError());
+  return IXTTS_OK;
+}
+
+int forward_rows(ixtts_gpt* h, int slot, int T, int pos0, int valid_from, hipStream_t st) {
+  if (T <= 0) return IXTTS_OK;
+  if (h->cfg.weight_dtype == IXTTS_DTYPE_F32) {
+    return h->D == 1280 ? forward_rows_t<float, float, 1280>(h, slot, T, pos0, valid_from, st)
+                        : forward_rows_t<float, float, 128>(h, slot, T, pos0, valid_from, st);
+  }
+  return h->D == 1280 ? forward_rows_t<bf16, bf16, 1280>(h, slot, T, pos0, valid_from, st)
+                      : forward_rows_t<bf16, bf16, 128>(h, slot, T, pos0, valid_from, st);
+}
+
+int final_norm_rows(ixtts_gpt* h, const float* x, float* y, int T, hipStream_t st) {
+  if (T <= 0) return IXTTS_OK;
+  if (h->D == 1280)
+    hipLaunchKernelGGL(final_norm_rows_kernel<1280>, dim3(ceil_div(T, 4)), dim3(256), 0, st, x, y, T, (const float*)A_F32(h->lnf_w),
+                       (const float*)A_F32(h->lnf_b), (const float*)A_F32(h->fn_w), (const float*)A_F32(h->fn_b));
+  else
+    hipLaunchKernelGGL(final_norm_rows_kernel<128>, dim3(ceil_div(T, 4)), dim3(256), 0, st, x, y, T, (const float*)A_F32(h->lnf_w),
+                       (const float*)A_F32(h->lnf_b), (const float*)A_F32(h->fn_w), (const float*)A_F32(h->fn_b));
+  IX_HIP(hipGetLastError());
+  return IXTTS_OK;
+}
+
+// rows of [start, codes...] embedded with mel positions 0..: x[r] = mel_emb[tok] + mel_pos[r]
+__global__ void embed_mel_rows_kernel(float* x, const float* mel_emb, const float* mel_pos, const int32_t* codes, int start_tok,
+                                      int rows, int D) {
+  const int r = blockIdx.x;
+  if (r >= rows) return;
+  const int tok = (r == 0) ? start_tok : codes[r - 1];
+  for (int i = threadIdx.x; i < D; i += blockDim.x) x[(size_t)r * D + i] = mel_emb[(size_t)tok * D + i] + mel_pos[(size_t)r * D + i];
+}
+
+int embed_mel_rows(ixtts_gpt* h, float* x, const int32_t* codes, int rows, hipStream_t st) {
+  if (rows <= 0) return IXTTS_OK;
+  hipLaunchKernelGGL(embed_mel_rows_kernel, dim3(rows), dim3(256), 0, st, x, (const float*)A_F32(h->mel_emb), (const float*)A_F32(h->mel_pos), codes,
+                     h->cfg.start_mel_token, rows, h->D);
+  IX_HIP(hipGetLastError());
+  return IXTTS_OK;
+}
+
+}  // namespace ixtts
