@@ -365,97 +365,149 @@ struct AttnArgs {
   int slot0, heads, smax, D;
 };
 
+// raw 16-element K/V slices (kept raw so IT iterations of loads stay in flight)
 template <typename KVT>
-__device__ __forceinline__ void load16(const KVT* p, float (&o)[16]);
+struct KVRaw;
 template <>
-__device__ __forceinline__ void load16<float>(const float* p, float (&o)[16]) {
+struct KVRaw<float> {
+  static constexpr int NV = 4, IT = 2;
+  uint4 r[4];
+  __device__ __forceinline__ void load(const float* p) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float4 v = reinterpret_cast<const float4*>(p)[i];
-    o[4 * i] = v.x; o[4 * i + 1] = v.y; o[4 * i + 2] = v.z; o[4 * i + 3] = v.w;
+    for (int i = 0; i < 4; ++i) r[i] = reinterpret_cast<const uint4*>(p)[i];
   }
-}
-template <>
-__device__ __forceinline__ void load16<bf16>(const bf16* p, float (&o)[16]) {
+  __device__ __forceinline__ void zero() {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    uint4 v = reinterpret_cast<const uint4*>(p)[i];
-    o[8 * i + 0] = lo_bf16(v.x); o[8 * i + 1] = hi_bf16(v.x); o[8 * i + 2] = lo_bf16(v.y); o[8 * i + 3] = hi_bf16(v.y);
-    o[8 * i + 4] = lo_bf16(v.z); o[8 * i + 5] = hi_bf16(v.z); o[8 * i + 6] = lo_bf16(v.w); o[8 * i + 7] = hi_bf16(v.w);
+    for (int i = 0; i < 4; ++i) r[i] = make_uint4(0u, 0u, 0u, 0u);
   }
-}
-
-template <typename KVT, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
-  __shared__ float sm[NW][4][2 + 16];  // [wave][dpart][m,l,acc16]
-  const int hh = blockIdx.x, slot = a.slot0 + blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pg = lane >> 2, dp = lane & 3;
-  const int p_end = a.cur_len[slot] + 1;
-  const int p_begin = a.valid_from[slot];
-
-  float qv[16];
-  {
-    const float* qp = a.q + (size_t)slot * a.D + hh * HD + dp * 16;
+  __device__ __forceinline__ void unpack(float (&o)[16]) const {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float4 t = reinterpret_cast<const float4*>(qp)[i];
-      qv[4 * i] = t.x * 0.125f; qv[4 * i + 1] = t.y * 0.125f; qv[4 * i + 2] = t.z * 0.125f; qv[4 * i + 3] = t.w * 0.125f;  // 1/sqrt(64)
+      o[4 * i] = __uint_as_float(r[i].x); o[4 * i + 1] = __uint_as_float(r[i].y);
+      o[4 * i + 2] = __uint_as_float(r[i].z); o[4 * i + 3] = __uint_as_float(r[i].w);
     }
   }
-  const KVT* kb = reinterpret_cast<const KVT*>(a.kcache) + ((size_t)slot * a.heads + hh) * a.smax * HD + dp * 16;
-  const KVT* vb = reinterpret_cast<const KVT*>(a.vcache) + ((size_t)slot * a.heads + hh) * a.smax * HD + dp * 16;
-
-  float m = -INFINITY, l = 0.f, acc[16];
+};
+template <>
+struct KVRaw<bf16> {
+  static constexpr int NV = 2, IT = 4;
+  uint4 r[2];
+  __device__ __forceinline__ void load(const bf16* p) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-
-  for (int p0 = p_begin + wave * 16; p0 < p_end; p0 += NW * 16) {
-    const int p = p0 + pg;
-    const bool ok = p < p_end;
-    float kv[16], vv[16];
-    float s = 0.f;
-    if (ok) {
-      load16<KVT>(kb + (size_t)p * HD, kv);
-      load16<KVT>(vb + (size_t)p * HD, vv);
+    for (int i = 0; i < 2; ++i) r[i] = reinterpret_cast<const uint4*>(p)[i];
+  }
+  __device__ __forceinline__ void zero() {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s = fmaf(qv[i], kv[i], s);
-    }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (ok) {
-      const float mn = fmaxf(m, s);
-      const float sc = expf(m - mn);  // exp(-inf) = 0 on the first hit
-      const float pw = expf(s - mn);
-      l = l * sc + pw;
+    for (int i = 0; i < 2; ++i) r[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __device__ __forceinline__ void unpack(float (&o)[16]) const {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = fmaf(acc[i], sc, pw * vv[i]);
-      m = mn;
+    for (int i = 0; i < 2; ++i) {
+      o[8 * i + 0] = lo_bf16(r[i].x); o[8 * i + 1] = hi_bf16(r[i].x); o[8 * i + 2] = lo_bf16(r[i].y); o[8 * i + 3] = hi_bf16(r[i].y);
+      o[8 * i + 4] = lo_bf16(r[i].z); o[8 * i + 5] = hi_bf16(r[i].z); o[8 * i + 6] = lo_bf16(r[i].w); o[8 * i + 7] = hi_bf16(r[i].w);
     }
   }
-  // merge the 16 position groups of the wave (lanes with equal dp): xor 4, 8, 16, 32
+};
+
+template <typename KVT>
+__device__ __forceinline__ void load16(const KVT* p, float (&o)[16]) {
+  KVRaw<KVT> t;
+  t.load(p);
+  t.unpack(o);
+}
+
+// Online-softmax state of one 4-lane group over the key positions it owns.
+struct SoftAcc {
+  float m, l, acc[16];
+  __device__ __forceinline__ void init() {
+    m = -INFINITY;
+    l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  }
+};
+
+// Sweep keys [p_begin, p_end) for one head: wave `wave` of NW takes 16-position groups round-robin;
+// IT groups of loads are issued before any is consumed.
+template <typename KVT, int NW>
+__device__ __forceinline__ void attn_sweep(SoftAcc& st, const KVT* kb, const KVT* vb, const float (&qv)[16], int p_begin,
+                                           int p_end, int wave, int pg) {
+  constexpr int IT = KVRaw<KVT>::IT;
+  for (int base = p_begin + wave * 16; base < p_end; base += NW * 16 * IT) {
+    KVRaw<KVT> kr[IT], vr[IT];
+    bool ok[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int p = base + it * NW * 16 + pg;
+      ok[it] = p < p_end;
+      if (ok[it]) {
+        kr[it].load(kb + (size_t)p * HD);
+        vr[it].load(vb + (size_t)p * HD);
+      } else {
+        kr[it].zero();
+        vr[it].zero();
+      }
+    }
+    float s[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      float kv[16];
+      kr[it].unpack(kv);
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) d = fmaf(qv[i], kv[i], d);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      s[it] = ok[it] ? d : -INFINITY;
+    }
+    float mn = st.m;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) mn = fmaxf(mn, s[it]);
+    if (mn > -INFINITY) {
+      const float sc = expf(st.m - mn);  // exp(-inf) = 0 on the first hit
+      st.l *= sc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st.acc[i] *= sc;
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const float pw = ok[it] ? expf(s[it] - mn) : 0.f;
+        float vv[16];
+        vr[it].unpack(vv);
+        st.l += pw;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st.acc[i] = fmaf(pw, vv[i], st.acc[i]);
+      }
+      st.m = mn;
+    }
+  }
+}
+
+// merge the 16 position groups of a wave, then the NW waves through LDS; thread d < 64 returns dim d
+template <int NW>
+__device__ __forceinline__ float attn_merge(SoftAcc& st, float (*sm)[4][2 + 16], int wave, int pg, int dp) {
 #pragma unroll
   for (int o = 4; o <= 32; o <<= 1) {
-    const float m2 = __shfl_xor(m, o, 64);
-    const float l2 = __shfl_xor(l, o, 64);
-    const float mn = fmaxf(m, m2);
-    const float s1 = (m > -INFINITY) ? expf(m - mn) : 0.f;
+    const float m2 = __shfl_xor(st.m, o, 64);
+    const float l2 = __shfl_xor(st.l, o, 64);
+    const float mn = fmaxf(st.m, m2);
+    const float s1 = (st.m > -INFINITY) ? expf(st.m - mn) : 0.f;
     const float s2 = (m2 > -INFINITY) ? expf(m2 - mn) : 0.f;
-    l = l * s1 + l2 * s2;
+    st.l = st.l * s1 + l2 * s2;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float a2 = __shfl_xor(acc[i], o, 64);
-      acc[i] = acc[i] * s1 + a2 * s2;
+      const float a2 = __shfl_xor(st.acc[i], o, 64);
+      st.acc[i] = st.acc[i] * s1 + a2 * s2;
     }
-    m = mn;
+    st.m = mn;
   }
   if (pg == 0) {
-    sm[wave][dp][0] = m;
-    sm[wave][dp][1] = l;
+    sm[wave][dp][0] = st.m;
+    sm[wave][dp][1] = st.l;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sm[wave][dp][2 + i] = acc[i];
+    for (int i = 0; i < 16; ++i) sm[wave][dp][2 + i] = st.acc[i];
   }
   __syncthreads();
+  float res = 0.f;
   if (threadIdx.x < 64) {
     const int d = threadIdx.x, dpp = d >> 4, di = d & 15;
     float M = -INFINITY;
@@ -471,8 +523,35 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
         O += sm[w][dpp][2 + di] * sc;
       }
     }
-    a.out[(size_t)slot * a.D + hh * HD + d] = O / L;
+    res = O / L;
   }
+  return res;
+}
+
+template <typename KVT, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
+  __shared__ float sm[NW][4][2 + 16];  // [wave][dpart][m,l,acc16]
+  const int hh = blockIdx.x, slot = a.slot0 + blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pg = lane >> 2, dp = lane & 3;
+  const int p_end = a.cur_len[slot] + 1;
+  const int p_begin = a.valid_from[slot];
+  float qv[16];
+  {
+    const float* qp = a.q + (size_t)slot * a.D + hh * HD + dp * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 t = reinterpret_cast<const float4*>(qp)[i];
+      qv[4 * i] = t.x * 0.125f; qv[4 * i + 1] = t.y * 0.125f; qv[4 * i + 2] = t.z * 0.125f; qv[4 * i + 3] = t.w * 0.125f;  // 1/sqrt(64)
+    }
+  }
+  const KVT* kb = reinterpret_cast<const KVT*>(a.kcache) + ((size_t)slot * a.heads + hh) * a.smax * HD + dp * 16;
+  const KVT* vb = reinterpret_cast<const KVT*>(a.vcache) + ((size_t)slot * a.heads + hh) * a.smax * HD + dp * 16;
+  SoftAcc st;
+  st.init();
+  attn_sweep<KVT, NW>(st, kb, vb, qv, p_begin, p_end, wave, pg);
+  const float o = attn_merge<NW>(st, sm, wave, pg, dp);
+  if (threadIdx.x < 64) a.out[(size_t)slot * a.D + hh * HD + threadIdx.x] = o;
 }
 
 #ifdef IXTTS_ENGINE_TU  // non-template kernels: compiled into gpt_engine.hip only

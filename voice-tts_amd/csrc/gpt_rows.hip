@@ -248,71 +248,11 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsArgs a) {
   }
   const KVT* kb = reinterpret_cast<const KVT*>(a.kcache) + (size_t)hh * a.smax * HD + dp * 16;
   const KVT* vb = reinterpret_cast<const KVT*>(a.vcache) + (size_t)hh * a.smax * HD + dp * 16;
-  float m = -INFINITY, l = 0.f, acc[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  for (int p0 = p_begin + wave * 16; p0 < p_end; p0 += NW * 16) {
-    const int p = p0 + pg;
-    const bool ok = p < p_end;
-    float kv[16], vv[16];
-    float s = 0.f;
-    if (ok) {
-      load16<KVT>(kb + (size_t)p * HD, kv);
-      load16<KVT>(vb + (size_t)p * HD, vv);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s = fmaf(qv[i], kv[i], s);
-    }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (ok) {
-      const float mn = fmaxf(m, s);
-      const float sc = expf(m - mn);
-      const float pw = expf(s - mn);
-      l = l * sc + pw;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = fmaf(acc[i], sc, pw * vv[i]);
-      m = mn;
-    }
-  }
-#pragma unroll
-  for (int o = 4; o <= 32; o <<= 1) {
-    const float m2 = __shfl_xor(m, o, 64);
-    const float l2 = __shfl_xor(l, o, 64);
-    const float mn = fmaxf(m, m2);
-    const float s1 = (m > -INFINITY) ? expf(m - mn) : 0.f;
-    const float s2 = (m2 > -INFINITY) ? expf(m2 - mn) : 0.f;
-    l = l * s1 + l2 * s2;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float a2 = __shfl_xor(acc[i], o, 64);
-      acc[i] = acc[i] * s1 + a2 * s2;
-    }
-    m = mn;
-  }
-  if (pg == 0) {
-    sm[wave][dp][0] = m;
-    sm[wave][dp][1] = l;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sm[wave][dp][2 + i] = acc[i];
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int d = threadIdx.x, dpp = d >> 4, di = d & 15;
-    float M = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) M = fmaxf(M, sm[w][dpp][0]);
-    float L = 0.f, O = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const float mw = sm[w][dpp][0];
-      if (mw > -INFINITY) {
-        const float sc = expf(mw - M);
-        L += sm[w][dpp][1] * sc;
-        O += sm[w][dpp][2 + di] * sc;
-      }
-    }
-    a.out[(size_t)row * a.D + hh * HD + d] = O / L;
-  }
+  SoftAcc st;
+  st.init();
+  attn_sweep<KVT, NW>(st, kb, vb, qv, p_begin, p_end, wave, pg);
+  const float o = attn_merge<NW>(st, sm, wave, pg, dp);
+  if (threadIdx.x < 64) a.out[(size_t)row * a.D + hh * HD + threadIdx.x] = o;
 }
 
 template <typename WT, typename KVT, int EPI>
