@@ -120,7 +120,7 @@ typedef struct ixtts_gpt_cfg {
 typedef struct ixtts_sampler_cfg {
   float repetition_penalty; /* 10.0 (infer_v2.py:605); 1.0 disables                         */
   float temperature;        /* 0.8; ignored when do_sample == 0                              */
-  int top_k;                /* 30;  "greedy" of BASELINE configs == do_sample 0  */
+  int top_k;                /* 30 (1..128 on the device); "greedy" of BASELINE configs == do_sample 0 or top_k 1 */
   float top_p;              /* 0.8                                                           */
   int do_sample;            /* 0: argmax of penalised logits; 1: multinomial after warpers   */
   int suppress_stop;        /* bench-only fixed-length mode: stop token forced to -inf       */
@@ -155,6 +155,9 @@ int ixtts_gpt_decode(ixtts_gpt* h, int n_active, int n_steps, const ixtts_sample
 int ixtts_gpt_read(ixtts_gpt* h, int b, int32_t* ids_host, int cap, int* n_ids, int* finished, void* stream);
 /* Raw fp32 logits of the most recent forward for slot b ([n_mel_codes], device -> host, sync). */
 int ixtts_gpt_read_logits(ixtts_gpt* h, int b, float* logits_host, void* stream);
+/* Probability vector [n_mel_codes] the last do_sample step drew from for slot b (after penalty,
+ * temperature, top-k, top-p, softmax; zeros for removed ids).  Parity-test hook. */
+int ixtts_gpt_read_probs(ixtts_gpt* h, int b, float* probs_host, void* stream);
 /* Teacher forcing for parity tests: overrides the NEXT token chosen for slot b. */
 int ixtts_gpt_force_next(ixtts_gpt* h, int b, int32_t token, void* stream);
 

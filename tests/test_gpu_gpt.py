@@ -75,6 +75,10 @@ def test_generate_surface_matches_reference_call(tiny_f32, dev):
     assert out[0, P:].tolist() == g["ids_padded"].tolist()
     with pytest.raises(NotImplementedError):
         eng.generate(fake, attention_mask=mask, max_length=P + 4, num_beams=3)
+    # sampling through the same surface (served defaults except num_beams): ids stay in range, length honoured
+    out2 = eng.generate(fake, attention_mask=mask, max_length=P + 12, do_sample=True, top_p=0.8, top_k=30, temperature=0.8,
+                        num_beams=1, repetition_penalty=10.0, seed=7)
+    assert out2.shape[1] <= P + 12 and int(out2[0, P:].max()) < 8194
 
 
 def test_teacher_forced_logits_vs_oracle(tiny_f32):
@@ -124,6 +128,48 @@ def test_stop_token_and_suppress(tiny_f32):
     eng.decode(1, 12, repetition_penalty=10.0, suppress_stop=True)
     ids, fin = eng.read(0)
     assert ids.tolist() == ref and not fin
+
+
+def test_sampling_distribution_vs_oracle(tiny_f32):
+    """Config 3: do_sample with repetition_penalty 10, temperature 0.8, top_k 30, top_p 0.8.
+    RNG cannot match torch's CPU stream, so parity is on the processed probability vector
+    (max-abs <= 1e-5) plus a frequency check of the draws."""
+    from oracle import gpt as OG
+
+    g, cfg, W, orc, eng = tiny_f32
+    embeds = torch.from_numpy(g["embeds_plain"])
+    mask = torch.from_numpy(g["mask_plain"])
+    P = len(mask)
+    forced = [11, 4097, 256]
+    eng.prefill(0, embeds, 0)
+    for tok in forced:
+        eng.force_next(0, tok)
+        eng.decode(1, 1, repetition_penalty=10.0)
+    logits = torch.from_numpy(eng.read_logits(0))
+    hist = [1] * (P - 1) + [8192] + forced
+    for (T, k, p) in [(0.8, 30, 0.8), (1.3, 5, 0.5), (0.8, 128, 1.0), (0.7, 1, 0.9)]:
+        ref = torch.softmax(OG.process_logits(logits, hist, 10.0, T, k, p, 1), -1).numpy()
+        counts = {}
+        n_draw = 160 if (T, k, p) == (0.8, 30, 0.8) else 3
+        for seed in range(n_draw):
+            eng.prefill(0, embeds, 0)
+            for tok in forced:
+                eng.force_next(0, tok)
+                eng.decode(1, 1, repetition_penalty=10.0)
+            eng.decode(1, 1, repetition_penalty=10.0, temperature=T, top_k=k, top_p=p, do_sample=True, seed=1000 + seed)
+            ids, _ = eng.read(0)
+            tok = int(ids[len(forced)])
+            counts[tok] = counts.get(tok, 0) + 1
+            assert ref[tok] > 0, (tok, T, k, p)  # every draw lies in the support the reference would sample from
+        probs = eng.read_probs(0)
+        assert np.abs(probs - ref).max() <= 1e-5, (T, k, p, np.abs(probs - ref).max())
+        assert (probs > 0).sum() == (ref > 0).sum()
+        if n_draw >= 100:
+            top = int(ref.argmax())
+            f = counts.get(top, 0) / n_draw
+            sigma = (ref[top] * (1 - ref[top]) / n_draw) ** 0.5
+            assert abs(f - ref[top]) <= 4.5 * sigma + 1e-9, (f, ref[top])
+            assert len(counts) > 1 or ref[top] > 0.97
 
 
 def test_latent_pass_vs_reference(tiny_f32, dev):

@@ -57,6 +57,7 @@ struct ixtts_gpt {
   int32_t* tokens = nullptr;
   uint8_t* seen = nullptr;
   ixtts_sampler_cfg* d_samp = nullptr;
+  float* probs = nullptr;  // [slots][V] processed probabilities of the last sampling step (parity tests)
   ixtts_sampler_cfg samp_host;
   float* scratch = nullptr;
   size_t scratch_floats = 0;

@@ -180,7 +180,8 @@ static void launch_sampler(ixtts_gpt* h, int n_active, hipStream_t st) {
   s.n_pos = h->cfg.n_mel_pos;
   s.stop = h->cfg.stop_mel_token;
   s.slot0 = 0;
-  hipLaunchKernelGGL(sampler_greedy_kernel, dim3(n_active), dim3(1024), 0, st, s);
+  s.probs_out = h->probs;
+  hipLaunchKernelGGL(sampler_kernel, dim3(n_active), dim3(1024), 0, st, s);
 }
 
 // dispatch on (dtype, D, B)
@@ -318,6 +319,7 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   ok &= hipMalloc(&h->tokens, (size_t)S * h->smax * 4) == hipSuccess;
   ok &= hipMalloc(&h->seen, (size_t)S * V) == hipSuccess;
   ok &= hipMalloc(&h->d_samp, sizeof(ixtts_sampler_cfg)) == hipSuccess;
+  ok &= hipMalloc(&h->probs, (size_t)S * V * 4) == hipSuccess;
   h->scratch_floats = (size_t)FF * D;
   ok &= hipMalloc(&h->scratch, h->scratch_floats * 4) == hipSuccess;
   if (!ok) return fail("state");
@@ -507,9 +509,10 @@ extern "C" int ixtts_gpt_decode(ixtts_gpt* h, int n_active, int n_steps, const i
   IX_ARG(n_active >= 1 && n_active <= h->cfg.max_batch, "gpt_decode: n_active %d", n_active);
   IX_ARG(n_steps >= 0, "gpt_decode: n_steps %d", n_steps);
   if (sc->do_sample) {
-    set_error("gpt_decode: do_sample=1 (top-k/top-p multinomial) is not implemented in this build");
-    return IXTTS_ERR_ARG;
+    IX_ARG(sc->top_k >= 1 && sc->top_k <= SAMP_MAXK, "gpt_decode: do_sample needs 1 <= top_k <= %d (got %d)", SAMP_MAXK, sc->top_k);
+    IX_ARG(sc->temperature > 0.f && sc->top_p > 0.f, "gpt_decode: temperature and top_p must be positive");
   }
+  IX_ARG(h->V <= 1024 * SAMP_PT, "gpt_decode: vocabulary %d exceeds the sampler tile", h->V);
   for (int b = 0; b < n_active; ++b) {
     IX_ARG(h->host_prompt_len[b] > 0, "gpt_decode: slot %d has no prefilled prompt", b);
     IX_ARG(h->host_prompt_len[b] + h->host_gen_est[b] + n_steps < h->smax, "gpt_decode: slot %d would overflow max_seq %d", b, h->smax);
@@ -553,6 +556,14 @@ extern "C" int ixtts_gpt_read_logits(ixtts_gpt* h, int b, float* out, void* stre
   IX_ARG(b >= 0 && b < h->cfg.max_batch && out, "gpt_read_logits: bad argument");
   IX_HIP(hipStreamSynchronize((hipStream_t)stream));
   IX_HIP(hipMemcpy(out, h->logits + (size_t)b * h->V, (size_t)h->V * 4, hipMemcpyDeviceToHost));
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_gpt_read_probs(ixtts_gpt* h, int b, float* out, void* stream) {
+  NEED_READY(h, "gpt_read_probs");
+  IX_ARG(b >= 0 && b < h->cfg.max_batch && out, "gpt_read_probs: bad argument");
+  IX_HIP(hipStreamSynchronize((hipStream_t)stream));
+  IX_HIP(hipMemcpy(out, h->probs + (size_t)b * h->V, (size_t)h->V * 4, hipMemcpyDeviceToHost));
   return IXTTS_OK;
 }
 
@@ -611,7 +622,7 @@ extern "C" int ixtts_gpt_destroy(ixtts_gpt* h) {
     if (h->step_exec[b]) hipGraphExecDestroy(h->step_exec[b]);
   if (h->cap_stream) hipStreamDestroy(h->cap_stream);
   void* ptrs[] = {h->arena, h->stage, h->kc, h->vc, h->h, h->q, h->ff, h->att, h->logits, h->rowbuf, h->cur_len, h->gen_count,
-                  h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->scratch,
+                  h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->probs, h->scratch,
                   h->rx, h->rxn, h->rq, h->ratt, h->rff};
   for (void* p : ptrs)
     if (p) hipFree(p);

@@ -570,30 +570,69 @@ struct SamplerState {
   const float* mel_emb; // [V][D]
   const float* mel_pos; // [n_pos][D]
   const ixtts_sampler_cfg* cfg;  // device copy
+  float* probs_out;     // optional [slots][V]: the processed probability vector (tests), or null
   int V, D, max_new, n_pos, stop, slot0;
 };
 
-__global__ __launch_bounds__(1024) void sampler_greedy_kernel(SamplerState s) {
+// float -> uint key with the same ordering (ascending)
+__device__ __forceinline__ unsigned int f2key(float x) {
+  const unsigned int b = __float_as_uint(x);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// counter-based uniform in [0,1): splitmix64 of (seed, slot, step)
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned int slot, unsigned int step) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (((unsigned long long)slot << 32) | (unsigned long long)(step + 1));
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+constexpr int SAMP_MAXK = 128;  // top_k supported on the device
+constexpr int SAMP_PT = 9;      // logits per thread (V <= 9216)
+
+// Processor chain in `_get_logits_processor` order (generation_utils.py:900-901,1020-1044):
+// [suppress] -> RepetitionPenalty -> Temperature -> TopK (ties with the k-th value kept) -> TopP -> softmax ->
+// multinomial(1)  |  argmax when do_sample == 0.
+__global__ __launch_bounds__(1024) void sampler_kernel(SamplerState s) {
   __shared__ float bv[16];
   __shared__ int bi[16];
   __shared__ int tok_s;
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int sel_prefix, sel_remaining;
+  __shared__ float cand_v[SAMP_MAXK], sort_v[SAMP_MAXK];
+  __shared__ int cand_i[SAMP_MAXK], sort_i[SAMP_MAXK];
+  __shared__ int cand_n;
+
   const int slot = s.slot0 + blockIdx.x;
-  const float theta = s.cfg->repetition_penalty;
-  const int suppress = s.cfg->suppress_stop;
+  const ixtts_sampler_cfg cfg = *s.cfg;
+  const float theta = cfg.repetition_penalty;
   const float* lg = s.logits + (size_t)slot * s.V;
   const uint8_t* seen = s.seen + (size_t)slot * s.V;
+  const bool sampling = cfg.do_sample != 0;
+  const float inv_t = (sampling && cfg.temperature > 0.f) ? 1.0f / cfg.temperature : 1.0f;
+
+  float vals[SAMP_PT];
   float best = -INFINITY;
   int besti = 0x7fffffff;
-  for (int v = threadIdx.x; v < s.V; v += 1024) {
-    float x = lg[v];
-    if (suppress && v == s.stop) x = -INFINITY;
-    if (seen[v]) x = (x < 0.f) ? x * theta : x / theta;  // RepetitionPenaltyLogitsProcessor
-    if (x > best || (x == best && v < besti)) {
-      best = x;
-      besti = v;
+#pragma unroll
+  for (int i = 0; i < SAMP_PT; ++i) {
+    const int v = threadIdx.x + i * 1024;
+    float x = -INFINITY;
+    if (v < s.V) {
+      x = lg[v];
+      if (cfg.suppress_stop && v == s.stop) x = -INFINITY;
+      if (seen[v] && theta != 1.0f) x = (x < 0.f) ? x * theta : x / theta;  // RepetitionPenaltyLogitsProcessor
+      if (sampling) x = x * inv_t;                                          // TemperatureLogitsWarper (x / T)
+      if (x > best || (x == best && v < besti)) {
+        best = x;
+        besti = v;
+      }
     }
+    vals[i] = x;
   }
-  // argmax with lowest-index tie break (torch.argmax returns the first maximal element)
+  // block argmax with lowest-index tie break (torch.argmax returns the first maximal element)
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     const float ob = __shfl_xor(best, o, 64);
@@ -607,6 +646,7 @@ __global__ __launch_bounds__(1024) void sampler_greedy_kernel(SamplerState s) {
     bv[threadIdx.x >> 6] = best;
     bi[threadIdx.x >> 6] = besti;
   }
+  if (threadIdx.x == 0) cand_n = 0;
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; ++w)
@@ -614,7 +654,109 @@ __global__ __launch_bounds__(1024) void sampler_greedy_kernel(SamplerState s) {
         best = bv[w];
         besti = bi[w];
       }
-    int tok = besti;
+    tok_s = besti;
+  }
+
+  if (sampling) {
+    // ---- TopK: exact k-th largest key by 4-pass MSB radix select
+    const int k = min(max(cfg.top_k, 1), SAMP_MAXK);
+    if (threadIdx.x == 0) {
+      sel_prefix = 0u;
+      sel_remaining = (unsigned int)k;
+    }
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+      __syncthreads();
+      const unsigned int prefix = sel_prefix;
+      const unsigned int pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+#pragma unroll
+      for (int i = 0; i < SAMP_PT; ++i) {
+        const int v = threadIdx.x + i * 1024;
+        if (v < s.V) {
+          const unsigned int key = f2key(vals[i]);
+          if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 0xffu], 1u);
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned int rem = sel_remaining, bin = 255;
+        for (;; --bin) {
+          const unsigned int c = hist[bin];
+          if (c >= rem || bin == 0) break;
+          rem -= c;
+        }
+        sel_prefix = prefix | (bin << shift);
+        sel_remaining = rem;
+      }
+      __syncthreads();
+    }
+    const unsigned int thr = sel_prefix;  // key of the k-th largest score; ties with it are kept (scores < kth removed)
+#pragma unroll
+    for (int i = 0; i < SAMP_PT; ++i) {
+      const int v = threadIdx.x + i * 1024;
+      if (v < s.V && f2key(vals[i]) >= thr && vals[i] > -INFINITY) {
+        const int pos = atomicAdd(&cand_n, 1);
+        if (pos < SAMP_MAXK) {
+          cand_v[pos] = vals[i];
+          cand_i[pos] = v;
+        }
+      }
+    }
+    __syncthreads();
+    const int n = min(cand_n, SAMP_MAXK);
+    // ---- sort survivors descending (value, then lower id first) by rank counting
+    if (threadIdx.x < n) {
+      const float mv = cand_v[threadIdx.x];
+      const int mi = cand_i[threadIdx.x];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        const float ov = cand_v[j];
+        const int oi = cand_i[j];
+        rank += (ov > mv || (ov == mv && oi < mi)) ? 1 : 0;
+      }
+      sort_v[rank] = mv;
+      sort_i[rank] = mi;
+    }
+    __syncthreads();
+    if (s.probs_out) {
+      float* po = s.probs_out + (size_t)slot * s.V;
+      for (int v = threadIdx.x; v < s.V; v += 1024) po[v] = 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && n > 0) {
+      // ---- TopP over the survivors: drop token r when sum_{q >= r} p_q <= 1 - top_p (ascending cumsum), keep >= 1
+      const float mx = sort_v[0];
+      float Z = 0.f;
+      for (int r = 0; r < n; ++r) Z += expf(sort_v[r] - mx);
+      int keep = n;
+      if (cfg.top_p < 1.0f) {
+        float tail = 0.f;
+        for (int r = n - 1; r >= 1; --r) {
+          tail += expf(sort_v[r] - mx) / Z;
+          if (tail <= 1.0f - cfg.top_p) keep = r;
+          else break;
+        }
+      }
+      float Zk = 0.f;
+      for (int r = 0; r < keep; ++r) Zk += expf(sort_v[r] - mx);
+      // ---- multinomial(1) by inverse CDF
+      const float u = uniform01(cfg.seed, (unsigned int)slot, (unsigned int)s.gen_count[slot]) * Zk;
+      float c = 0.f;
+      int pick = -1;
+      for (int r = 0; r < keep; ++r) {
+        const float pr = expf(sort_v[r] - mx);
+        if (s.probs_out) s.probs_out[(size_t)slot * s.V + sort_i[r]] = pr / Zk;
+        c += pr;
+        if (pick < 0 && u < c) pick = sort_i[r];
+      }
+      if (pick < 0) pick = sort_i[keep - 1];
+      tok_s = pick;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tok = tok_s;
     if (s.finished[slot]) tok = s.stop;  // finished rows keep emitting pad == stop (generation_utils.py:3255-3256)
     if (s.forced[slot] >= 0) {
       tok = s.forced[slot];

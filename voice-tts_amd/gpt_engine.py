@@ -106,6 +106,12 @@ class GptEngine:
             _lib.check(_lib.lib().ixtts_gpt_read_logits(self._h, slot, out.ctypes.data, self._stream()), "ixtts_gpt_read_logits")
         return out
 
+    def read_probs(self, slot):
+        out = np.zeros(self.V, dtype=np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ixtts_gpt_read_probs(self._h, slot, out.ctypes.data, self._stream()), "ixtts_gpt_read_probs")
+        return out
+
     def force_next(self, slot, token):
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().ixtts_gpt_force_next(self._h, slot, int(token), self._stream()), "ixtts_gpt_force_next")
@@ -152,8 +158,8 @@ class GptEngine:
         if inputs.shape[0] != 1 or num_return_sequences != 1:
             raise NotImplementedError("one sequence per generate() call (autoregressive_batch_size = 1, infer_v2.py:602)")
         greedy = (not do_sample) or top_k == 1
-        if not greedy:
-            raise NotImplementedError("top-k/top-p multinomial sampling is not implemented in the HIP engine yet")
+        if not greedy and not (1 <= top_k <= 128):
+            raise NotImplementedError("device sampler supports 1 <= top_k <= 128 (top_k=0 'disabled' is not implemented)")
         P = inputs.shape[1]
         emb = self.cached_mel_emb
         emb = emb[0] if emb.dim() == 3 else emb
@@ -170,7 +176,8 @@ class GptEngine:
         ids, fin = np.zeros(0, np.int32), False
         while done < max_new and not fin:
             n = min(sync_every, max_new - done)
-            self.decode(1, n, repetition_penalty=repetition_penalty, do_sample=False, suppress_stop=suppress_stop)
+            self.decode(1, n, repetition_penalty=repetition_penalty, temperature=temperature, top_k=top_k, top_p=top_p,
+                        do_sample=not greedy, suppress_stop=suppress_stop, seed=int(unused.get("seed", 0)))
             done += n
             ids, fin = self.read(0)
         ids = ids[:max_new]
