@@ -48,7 +48,8 @@ struct ixtts_gpt {
   std::map<std::string, ixtts::TDesc> tens;
   bool finalized = false;
   // state
-  float *h = nullptr, *q = nullptr, *ff = nullptr, *att = nullptr, *logits = nullptr, *rowbuf = nullptr;
+  float *h = nullptr, *q = nullptr, *ff = nullptr, *att = nullptr, *part = nullptr, *logits = nullptr, *rowbuf = nullptr;
+  int nsplit[ixtts::MAXB + 1];  // split-S factor of the decode attention per batch size
   float* stage = nullptr;  // fp32 [N][K] staging of every matrix until finalize folds/converts it
   size_t stage_floats = 0;
   void *kc = nullptr, *vc = nullptr;

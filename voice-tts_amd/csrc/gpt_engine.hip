@@ -79,9 +79,14 @@ static int gemv_out(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.bias = A_F32(o.bo);
   a.N = D;
   a.slot0 = slot0;
-  a.xin = h->att;
   a.out = h->h;
   a.out_stride = D;
+  a.nsplit = h->nsplit[B];
+  if (a.nsplit > 1) {
+    a.xin = h->part;
+    return launch_gemv<WT, KVT, D, DM::R1, DM::U_OUT, B, IN_ATTN, EPI_RESID>(a, st);
+  }
+  a.xin = h->att;
   return launch_gemv<WT, KVT, D, DM::R1, DM::U_OUT, B, IN_PLAIN, EPI_RESID>(a, st);
 }
 
@@ -144,14 +149,18 @@ static int forward_layers(ixtts_gpt* h, int slot0, hipStream_t st) {
     t.q = h->q;
     t.kcache = (uint8_t*)h->kc + l * lstride;
     t.vcache = (uint8_t*)h->vc + l * lstride;
-    t.out = h->att;
+    t.nsplit = h->nsplit[B];
+    t.out = t.nsplit > 1 ? h->part : h->att;
     t.cur_len = h->cur_len;
     t.valid_from = h->valid_from;
     t.slot0 = slot0;
     t.heads = h->H;
     t.smax = h->smax;
     t.D = D;
-    hipLaunchKernelGGL((attn_decode_kernel<KVT, 16>), dim3(h->H, B), dim3(1024), 0, st, t);
+    // measured r01 (B=2, bf16): 8 waves x 4 row-groups in flight is the best compromise between the
+    // speculative first pass at short context (5.4 us at S=160) and the stream at long context (12.6 us at S=1220)
+    if (t.nsplit > 1) hipLaunchKernelGGL((attn_decode_kernel<KVT, 4, 8>), dim3(h->H, t.nsplit, B), dim3(256), 0, st, t);
+    else hipLaunchKernelGGL((attn_decode_kernel<KVT, 8, 4>), dim3(h->H, 1, B), dim3(512), 0, st, t);
     IX_TRY((gemv_out<WT, KVT, D, B>(h, l, slot0, st)));
     IX_TRY((gemv_fc<WT, KVT, D, B>(h, l, slot0, st)));
     IX_TRY((gemv_pr<WT, KVT, D, B>(h, l, slot0, st)));
@@ -303,6 +312,7 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   ok &= hipMalloc(&h->q, (size_t)S * D * 4) == hipSuccess;
   ok &= hipMalloc(&h->ff, (size_t)S * FF * 4) == hipSuccess;
   ok &= hipMalloc(&h->att, (size_t)S * D * 4) == hipSuccess;
+  ok &= hipMalloc(&h->part, (size_t)S * h->H * NSPLIT_MAX * PART_STRIDE * 4) == hipSuccess;
   ok &= hipMalloc(&h->logits, (size_t)S * V * 4) == hipSuccess;
   ok &= hipMalloc(&h->rowbuf, (size_t)D * 4) == hipSuccess;
   ok &= hipMalloc(&h->rx, (size_t)h->smax * D * 4) == hipSuccess;
@@ -332,6 +342,12 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   hipMemset(h->seen, 0, (size_t)S * V);
   hipMemset(h->logits, 0, (size_t)S * V * 4);
   if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
+  // split-S factor of the decode attention (IXTTS_NSPLIT overrides, for A/B timing and the split-path test)
+  for (int b = 1; b <= MAXB; ++b) {
+    int ns = 1;  // measured r01: consumer-side merge costs more than the split saves at S <= 1300
+    if (const char* e = getenv("IXTTS_NSPLIT")) ns = std::max(1, std::min(NSPLIT_MAX, atoi(e)));
+    h->nsplit[b] = ns;
+  }
   memset(h->host_prompt_len, 0, sizeof(h->host_prompt_len));
   memset(h->host_gen_est, 0, sizeof(h->host_gen_est));
   *out = h;
@@ -621,7 +637,7 @@ extern "C" int ixtts_gpt_destroy(ixtts_gpt* h) {
   for (int b = 0; b <= MAXB; ++b)
     if (h->step_exec[b]) hipGraphExecDestroy(h->step_exec[b]);
   if (h->cap_stream) hipStreamDestroy(h->cap_stream);
-  void* ptrs[] = {h->arena, h->stage, h->kc, h->vc, h->h, h->q, h->ff, h->att, h->logits, h->rowbuf, h->cur_len, h->gen_count,
+  void* ptrs[] = {h->arena, h->stage, h->kc, h->vc, h->h, h->q, h->ff, h->att, h->part, h->logits, h->rowbuf, h->cur_len, h->gen_count,
                   h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->probs, h->scratch,
                   h->rx, h->rxn, h->rq, h->ratt, h->rff};
   for (void* p : ptrs)

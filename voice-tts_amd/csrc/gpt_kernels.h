@@ -24,7 +24,11 @@ namespace ixtts {
 
 constexpr int HD = 64;  // head dim (asserted at create)
 
-enum { IN_LN = 0, IN_LN2 = 1, IN_PLAIN = 2 };
+enum { IN_LN = 0, IN_LN2 = 1, IN_PLAIN = 2, IN_ATTN = 3 };
+
+// split-S attention partials: per (slot, head, split) [m, l, pad, pad, acc[64]] (acc 16-byte aligned)
+constexpr int PART_STRIDE = 4 + 64;
+constexpr int NSPLIT_MAX = 8;
 enum { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3 };
 
 struct GemvArgs {
@@ -32,7 +36,9 @@ struct GemvArgs {
   const float* bias;    // [N] (LN bias pre-folded)
   int N;
   int slot0;            // first sequence slot
-  const float* xin;     // [slots][K]: residual stream h (IN_LN*), attention output / ff (IN_PLAIN)
+  const float* xin;     // [slots][K]: residual stream h (IN_LN*), attention output / ff (IN_PLAIN);
+                        // IN_ATTN: split-S partials [slots][H][nsplit][PART_STRIDE]
+  int nsplit;           // IN_ATTN
   const float* ln_w;    // IN_LN2 only: explicit gain/bias of the FIRST norm (ln_f)
   const float* ln_b;
   float* out;           // EPI_RESID: h (in place add); EPI_GELU: ff; EPI_LOGITS: logits; EPI_QKV: q
@@ -129,17 +135,54 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(GemvArgs a) {
 
   // ---- 1. activation slice -> registers (L2-resident, issued first: vmcnt retires in order)
   float xr[B][NL][VEC];
+  if constexpr (INP == IN_ATTN) {
+    // flash-decode merge of the split-S partials, straight into the lane's slice:
+    // x[k] = sum_s acc_s[k] e^{m_s - M} / sum_s l_s e^{m_s - M}
+    constexpr int H = K / HD;
 #pragma unroll
-  for (int b = 0; b < B; ++b) {
-    const float* xs = a.xin + (size_t)(a.slot0 + b) * K;
+    for (int b = 0; b < B; ++b) {
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      const int e = j * PER + lane * VEC;
-      const int k0 = e % K;
+      for (int j = 0; j < NL; ++j) {
+        const int k0 = (j * PER + lane * VEC) % K;
+        const int hh = k0 / HD, d0 = k0 % HD;
+        const float* p = a.xin + ((size_t)((a.slot0 + b) * H + hh) * a.nsplit) * PART_STRIDE;
+        float M = -INFINITY;
+        for (int sidx = 0; sidx < a.nsplit; ++sidx) M = fmaxf(M, p[sidx * PART_STRIDE]);
+        float L = 0.f, o[VEC];
 #pragma unroll
-      for (int v4 = 0; v4 < VEC / 4; ++v4) {
-        const float4 t = *reinterpret_cast<const float4*>(xs + k0 + v4 * 4);
-        xr[b][j][v4 * 4 + 0] = t.x; xr[b][j][v4 * 4 + 1] = t.y; xr[b][j][v4 * 4 + 2] = t.z; xr[b][j][v4 * 4 + 3] = t.w;
+        for (int v = 0; v < VEC; ++v) o[v] = 0.f;
+        for (int sidx = 0; sidx < a.nsplit; ++sidx) {
+          const float* ps = p + sidx * PART_STRIDE;
+          const float2 ml = *reinterpret_cast<const float2*>(ps);
+          const float w = (ml.x > -INFINITY) ? expf(ml.x - M) : 0.f;
+          L = fmaf(ml.y, w, L);
+#pragma unroll
+          for (int v4 = 0; v4 < VEC / 4; ++v4) {
+            const float4 t = *reinterpret_cast<const float4*>(ps + 4 + d0 + v4 * 4);
+            o[v4 * 4 + 0] = fmaf(t.x, w, o[v4 * 4 + 0]);
+            o[v4 * 4 + 1] = fmaf(t.y, w, o[v4 * 4 + 1]);
+            o[v4 * 4 + 2] = fmaf(t.z, w, o[v4 * 4 + 2]);
+            o[v4 * 4 + 3] = fmaf(t.w, w, o[v4 * 4 + 3]);
+          }
+        }
+        const float inv = 1.0f / L;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) xr[b][j][v] = o[v] * inv;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const float* xs = a.xin + (size_t)(a.slot0 + b) * K;
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const int e = j * PER + lane * VEC;
+        const int k0 = e % K;
+#pragma unroll
+        for (int v4 = 0; v4 < VEC / 4; ++v4) {
+          const float4 t = *reinterpret_cast<const float4*>(xs + k0 + v4 * 4);
+          xr[b][j][v4 * 4 + 0] = t.x; xr[b][j][v4 * 4 + 1] = t.y; xr[b][j][v4 * 4 + 2] = t.z; xr[b][j][v4 * 4 + 3] = t.w;
+        }
       }
     }
   }
@@ -359,105 +402,81 @@ struct AttnArgs {
   const float* q;       // [slots][D]
   const void* kcache;   // layer base: [slots][H][smax][64]
   const void* vcache;
-  float* out;           // [slots][D]
+  float* out;           // nsplit == 1: [slots][D] normalised; else partials [slots][H][nsplit][PART_STRIDE]
   const int* cur_len;
   const int* valid_from;
-  int slot0, heads, smax, D;
+  int slot0, heads, smax, D, nsplit;
 };
 
-// raw 16-element K/V slices (kept raw so IT iterations of loads stay in flight)
+// ---- attention building blocks -------------------------------------------------------
+// Lane layout: every lane owns ONE 16-byte slice of a key/value row, so a wave-instruction
+// reads whole rows back to back (bf16: 8 lanes x 8 dims per key, 8 keys = 1 KiB contiguous;
+// fp32: 16 lanes x 4 dims, 4 keys).  IT row groups of loads are issued before any is consumed.
 template <typename KVT>
-struct KVRaw;
-template <>
-struct KVRaw<float> {
-  static constexpr int NV = 4, IT = 2;
-  uint4 r[4];
-  __device__ __forceinline__ void load(const float* p) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = reinterpret_cast<const uint4*>(p)[i];
-  }
-  __device__ __forceinline__ void zero() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = make_uint4(0u, 0u, 0u, 0u);
-  }
-  __device__ __forceinline__ void unpack(float (&o)[16]) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      o[4 * i] = __uint_as_float(r[i].x); o[4 * i + 1] = __uint_as_float(r[i].y);
-      o[4 * i + 2] = __uint_as_float(r[i].z); o[4 * i + 3] = __uint_as_float(r[i].w);
-    }
-  }
+struct KVLayout {
+  static constexpr int DPL = 16 / sizeof(KVT);  // dims per lane
+  static constexpr int LPP = HD / DPL;          // lanes per key position
+  static constexpr int PPW = 64 / LPP;          // key positions per wave-instruction
 };
-template <>
-struct KVRaw<bf16> {
-  static constexpr int NV = 2, IT = 4;
-  uint4 r[2];
-  __device__ __forceinline__ void load(const bf16* p) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) r[i] = reinterpret_cast<const uint4*>(p)[i];
-  }
-  __device__ __forceinline__ void zero() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) r[i] = make_uint4(0u, 0u, 0u, 0u);
-  }
-  __device__ __forceinline__ void unpack(float (&o)[16]) const {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      o[8 * i + 0] = lo_bf16(r[i].x); o[8 * i + 1] = hi_bf16(r[i].x); o[8 * i + 2] = lo_bf16(r[i].y); o[8 * i + 3] = hi_bf16(r[i].y);
-      o[8 * i + 4] = lo_bf16(r[i].z); o[8 * i + 5] = hi_bf16(r[i].z); o[8 * i + 6] = lo_bf16(r[i].w); o[8 * i + 7] = hi_bf16(r[i].w);
-    }
-  }
-};
-
-template <typename KVT>
-__device__ __forceinline__ void load16(const KVT* p, float (&o)[16]) {
-  KVRaw<KVT> t;
-  t.load(p);
-  t.unpack(o);
+__device__ __forceinline__ void kv_unpack(const uint4& r, float (&o)[4]) {
+  o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y); o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
+}
+__device__ __forceinline__ void kv_unpack(const uint4& r, float (&o)[8]) {
+  o[0] = lo_bf16(r.x); o[1] = hi_bf16(r.x); o[2] = lo_bf16(r.y); o[3] = hi_bf16(r.y);
+  o[4] = lo_bf16(r.z); o[5] = hi_bf16(r.z); o[6] = lo_bf16(r.w); o[7] = hi_bf16(r.w);
 }
 
-// Online-softmax state of one 4-lane group over the key positions it owns.
+// Online-softmax state of one lane group over the key positions it owns.
+template <int DPL>
 struct SoftAcc {
-  float m, l, acc[16];
+  float m, l, acc[DPL];
   __device__ __forceinline__ void init() {
     m = -INFINITY;
     l = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
   }
 };
 
-// Sweep keys [p_begin, p_end) for one head: wave `wave` of NW takes 16-position groups round-robin;
-// IT groups of loads are issued before any is consumed.
-template <typename KVT, int NW>
-__device__ __forceinline__ void attn_sweep(SoftAcc& st, const KVT* kb, const KVT* vb, const float (&qv)[16], int p_begin,
-                                           int p_end, int wave, int pg) {
-  constexpr int IT = KVRaw<KVT>::IT;
-  for (int base = p_begin + wave * 16; base < p_end; base += NW * 16 * IT) {
-    KVRaw<KVT> kr[IT], vr[IT];
+// Sweep keys [p_lo, p_hi) of one head (positions are absolute cache rows).  Wave `wave` of NW takes
+// PPW-row groups round-robin.  The FIRST pass is issued before p_lo / p_hi are known (`bounds` is
+// called after the loads are in flight), which takes one dependent global-load latency off the
+// critical path; rows outside [p_lo, p_hi) are masked, addresses are clamped to the cache.
+template <typename KVT, int NW, int IT, typename BoundsFn>
+__device__ __forceinline__ void attn_sweep(SoftAcc<KVLayout<KVT>::DPL>& st, const KVT* kb, const KVT* vb,
+                                           const float (&qv)[KVLayout<KVT>::DPL], int smax, int wave, int lane, BoundsFn bounds) {
+  using LY = KVLayout<KVT>;
+  constexpr int DPL = LY::DPL, LPP = LY::LPP, PPW = LY::PPW;
+  const int pg = lane / LPP;
+  int p_lo = 0, p_hi = 0;
+  bool have_bounds = false;
+  for (int base = 0;; base += NW * PPW * IT) {
+    if (have_bounds && base >= p_hi) break;
+    uint4 kr[IT], vr[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int p = base + (it * NW + wave) * PPW + pg;
+      const size_t off = (size_t)min(p, smax - 1) * HD;
+      kr[it] = *reinterpret_cast<const uint4*>(kb + off);
+      vr[it] = *reinterpret_cast<const uint4*>(vb + off);
+    }
+    if (!have_bounds) {
+      bounds(p_lo, p_hi);
+      have_bounds = true;
+    }
+    float s[IT];
     bool ok[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      const int p = base + it * NW * 16 + pg;
-      ok[it] = p < p_end;
-      if (ok[it]) {
-        kr[it].load(kb + (size_t)p * HD);
-        vr[it].load(vb + (size_t)p * HD);
-      } else {
-        kr[it].zero();
-        vr[it].zero();
-      }
-    }
-    float s[IT];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      float kv[16];
-      kr[it].unpack(kv);
+      const int p = base + (it * NW + wave) * PPW + pg;
+      ok[it] = (p >= p_lo) && (p < p_hi);
+      float kv[DPL];
+      kv_unpack(kr[it], kv);
       float d = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) d = fmaf(qv[i], kv[i], d);
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
+      for (int i = 0; i < DPL; ++i) d = fmaf(qv[i], kv[i], d);
+#pragma unroll
+      for (int o = 1; o < LPP; o <<= 1) d += __shfl_xor(d, o, 64);
       s[it] = ok[it] ? d : -INFINITY;
     }
     float mn = st.m;
@@ -467,26 +486,31 @@ __device__ __forceinline__ void attn_sweep(SoftAcc& st, const KVT* kb, const KVT
       const float sc = expf(st.m - mn);  // exp(-inf) = 0 on the first hit
       st.l *= sc;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) st.acc[i] *= sc;
+      for (int i = 0; i < DPL; ++i) st.acc[i] *= sc;
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
         const float pw = ok[it] ? expf(s[it] - mn) : 0.f;
-        float vv[16];
-        vr[it].unpack(vv);
+        float vv[DPL];
+        kv_unpack(vr[it], vv);
         st.l += pw;
+        // rows outside the range were read speculatively and may hold anything (NaN/Inf bit patterns): 0 * NaN != 0
 #pragma unroll
-        for (int i = 0; i < 16; ++i) st.acc[i] = fmaf(pw, vv[i], st.acc[i]);
+        for (int i = 0; i < DPL; ++i) st.acc[i] = fmaf(pw, ok[it] ? vv[i] : 0.f, st.acc[i]);
       }
       st.m = mn;
     }
   }
 }
 
-// merge the 16 position groups of a wave, then the NW waves through LDS; thread d < 64 returns dim d
-template <int NW>
-__device__ __forceinline__ float attn_merge(SoftAcc& st, float (*sm)[4][2 + 16], int wave, int pg, int dp) {
+// merge the PPW position groups of a wave, then the NW waves through LDS; thread d < 64 gets dim d
+template <typename KVT, int NW>
+__device__ __forceinline__ float attn_merge(SoftAcc<KVLayout<KVT>::DPL>& st, float (*sm)[KVLayout<KVT>::LPP][2 + KVLayout<KVT>::DPL],
+                                            int wave, int lane, float* outM = nullptr, float* outL = nullptr, float* outO = nullptr) {
+  using LY = KVLayout<KVT>;
+  constexpr int DPL = LY::DPL, LPP = LY::LPP;
+  const int pg = lane / LPP, dp = lane % LPP;
 #pragma unroll
-  for (int o = 4; o <= 32; o <<= 1) {
+  for (int o = LPP; o <= 32; o <<= 1) {
     const float m2 = __shfl_xor(st.m, o, 64);
     const float l2 = __shfl_xor(st.l, o, 64);
     const float mn = fmaxf(st.m, m2);
@@ -494,7 +518,7 @@ __device__ __forceinline__ float attn_merge(SoftAcc& st, float (*sm)[4][2 + 16],
     const float s2 = (m2 > -INFINITY) ? expf(m2 - mn) : 0.f;
     st.l = st.l * s1 + l2 * s2;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < DPL; ++i) {
       const float a2 = __shfl_xor(st.acc[i], o, 64);
       st.acc[i] = st.acc[i] * s1 + a2 * s2;
     }
@@ -504,12 +528,12 @@ __device__ __forceinline__ float attn_merge(SoftAcc& st, float (*sm)[4][2 + 16],
     sm[wave][dp][0] = st.m;
     sm[wave][dp][1] = st.l;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sm[wave][dp][2 + i] = st.acc[i];
+    for (int i = 0; i < DPL; ++i) sm[wave][dp][2 + i] = st.acc[i];
   }
   __syncthreads();
   float res = 0.f;
   if (threadIdx.x < 64) {
-    const int d = threadIdx.x, dpp = d >> 4, di = d & 15;
+    const int d = threadIdx.x, dpp = d / DPL, di = d % DPL;
     float M = -INFINITY;
 #pragma unroll
     for (int w = 0; w < NW; ++w) M = fmaxf(M, sm[w][dpp][0]);
@@ -524,34 +548,68 @@ __device__ __forceinline__ float attn_merge(SoftAcc& st, float (*sm)[4][2 + 16],
       }
     }
     res = O / L;
+    if (outM) {
+      *outM = M;
+      *outL = L;
+      *outO = O;
+    }
   }
   return res;
 }
 
-template <typename KVT, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
-  __shared__ float sm[NW][4][2 + 16];  // [wave][dpart][m,l,acc16]
-  const int hh = blockIdx.x, slot = a.slot0 + blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pg = lane >> 2, dp = lane & 3;
-  const int p_end = a.cur_len[slot] + 1;
-  const int p_begin = a.valid_from[slot];
-  float qv[16];
-  {
-    const float* qp = a.q + (size_t)slot * a.D + hh * HD + dp * 16;
+template <typename KVT>
+__device__ __forceinline__ void load_q_slice(const float* qp, int dp, float (&qv)[KVLayout<KVT>::DPL]) {
+  constexpr int DPL = KVLayout<KVT>::DPL;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 t = reinterpret_cast<const float4*>(qp)[i];
-      qv[4 * i] = t.x * 0.125f; qv[4 * i + 1] = t.y * 0.125f; qv[4 * i + 2] = t.z * 0.125f; qv[4 * i + 3] = t.w * 0.125f;  // 1/sqrt(64)
+  for (int i = 0; i < DPL / 4; ++i) {
+    const float4 t = reinterpret_cast<const float4*>(qp + dp * DPL)[i];
+    qv[4 * i] = t.x * 0.125f; qv[4 * i + 1] = t.y * 0.125f; qv[4 * i + 2] = t.z * 0.125f; qv[4 * i + 3] = t.w * 0.125f;  // 1/sqrt(64)
+  }
+}
+
+template <typename KVT, int NW, int IT>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
+  using LY = KVLayout<KVT>;
+  __shared__ float sm[NW][LY::LPP][2 + LY::DPL];
+  const int hh = blockIdx.x, split = blockIdx.y, slot = a.slot0 + blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int dp = lane % LY::LPP;
+  // scalar state first (its latency overlaps the first K/V pass), then q, then the K/V stream
+  const int cur = a.cur_len[slot];
+  const int vf = a.valid_from[slot];
+  float qv[LY::DPL];
+  load_q_slice<KVT>(a.q + (size_t)slot * a.D + hh * HD, dp, qv);
+  const KVT* kb = reinterpret_cast<const KVT*>(a.kcache) + ((size_t)slot * a.heads + hh) * a.smax * HD + dp * LY::DPL;
+  const KVT* vb = reinterpret_cast<const KVT*>(a.vcache) + ((size_t)slot * a.heads + hh) * a.smax * HD + dp * LY::DPL;
+  SoftAcc<LY::DPL> st;
+  st.init();
+  const int nsplit = a.nsplit;
+  attn_sweep<KVT, NW, IT>(st, kb, vb, qv, a.smax, wave, lane, [&](int& lo, int& hi) {
+    const int S_end = cur + 1;
+    if (nsplit == 1) {
+      lo = vf;
+      hi = S_end;
+    } else {  // an equal share of [valid_from, cur_len], rounded to 16-key groups
+      const int chunk = (((S_end - vf + nsplit - 1) / nsplit) + 15) & ~15;
+      lo = vf + split * chunk;
+      hi = min(S_end, lo + chunk);
+    }
+  });
+  float M, L, O;
+  const float o = attn_merge<KVT, NW>(st, sm, wave, lane, &M, &L, &O);
+  if (threadIdx.x < 64) {
+    if (nsplit == 1) {
+      a.out[(size_t)slot * a.D + hh * HD + threadIdx.x] = o;
+    } else {
+      // an empty range leaves M = -inf, L = 0, O = 0: the consumer gives it weight 0
+      float* pp = a.out + (((size_t)slot * a.heads + hh) * nsplit + split) * PART_STRIDE;
+      if (threadIdx.x == 0) {
+        pp[0] = M;
+        pp[1] = L;
+      }
+      pp[4 + threadIdx.x] = O;
     }
   }
-  const KVT* kb = reinterpret_cast<const KVT*>(a.kcache) + ((size_t)slot * a.heads + hh) * a.smax * HD + dp * 16;
-  const KVT* vb = reinterpret_cast<const KVT*>(a.vcache) + ((size_t)slot * a.heads + hh) * a.smax * HD + dp * 16;
-  SoftAcc st;
-  st.init();
-  attn_sweep<KVT, NW>(st, kb, vb, qv, p_begin, p_end, wave, pg);
-  const float o = attn_merge<NW>(st, sm, wave, pg, dp);
-  if (threadIdx.x < 64) a.out[(size_t)slot * a.D + hh * HD + threadIdx.x] = o;
 }
 
 #ifdef IXTTS_ENGINE_TU  // non-template kernels: compiled into gpt_engine.hip only

@@ -231,27 +231,23 @@ struct AttnRowsArgs {
 template <typename KVT>
 __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsArgs a) {
   constexpr int NW = 4;
-  __shared__ float sm[NW][4][2 + 16];
+  using LY = KVLayout<KVT>;
+  __shared__ float sm[NW][LY::LPP][2 + LY::DPL];
   const int hh = blockIdx.x, row = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pg = lane >> 2, dp = lane & 3;
-  const int p_end = a.pos0 + row + 1;
-  const int p_begin = a.valid_from;
-  float qv[16];
-  {
-    const float* qp = a.q + (size_t)row * a.D + hh * HD + dp * 16;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 t = reinterpret_cast<const float4*>(qp)[i];
-      qv[4 * i] = t.x * 0.125f; qv[4 * i + 1] = t.y * 0.125f; qv[4 * i + 2] = t.z * 0.125f; qv[4 * i + 3] = t.w * 0.125f;
-    }
-  }
-  const KVT* kb = reinterpret_cast<const KVT*>(a.kcache) + (size_t)hh * a.smax * HD + dp * 16;
-  const KVT* vb = reinterpret_cast<const KVT*>(a.vcache) + (size_t)hh * a.smax * HD + dp * 16;
-  SoftAcc st;
+  const int dp = lane % LY::LPP;
+  float qv[LY::DPL];
+  load_q_slice<KVT>(a.q + (size_t)row * a.D + hh * HD, dp, qv);
+  const KVT* kb = reinterpret_cast<const KVT*>(a.kcache) + (size_t)hh * a.smax * HD + dp * LY::DPL;
+  const KVT* vb = reinterpret_cast<const KVT*>(a.vcache) + (size_t)hh * a.smax * HD + dp * LY::DPL;
+  SoftAcc<LY::DPL> st;
   st.init();
-  attn_sweep<KVT, NW>(st, kb, vb, qv, p_begin, p_end, wave, pg);
-  const float o = attn_merge<NW>(st, sm, wave, pg, dp);
+  const int lo0 = a.valid_from, hi0 = a.pos0 + row + 1;
+  attn_sweep<KVT, NW, 8>(st, kb, vb, qv, a.smax, wave, lane, [&](int& lo, int& hi) {
+    lo = lo0;
+    hi = hi0;
+  });
+  const float o = attn_merge<KVT, NW>(st, sm, wave, lane);
   if (threadIdx.x < 64) a.out[(size_t)row * a.D + hh * HD + threadIdx.x] = o;
 }
 
