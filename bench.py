@@ -185,13 +185,28 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (reps * L)
         achieved = alg_bytes / (us * 1e-6) / 1e9
+        # HBM traffic per launch of the same kernel from the committed PMC passes (tools/pmc_traffic.py; separate
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 FETCH correction) -- null if no pass matches
+        traffic = None
+        try:
+            import glob
+
+            wt = "__hip_bfloat16" if args.dtype == "bf16" else "float"
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[::-1]:
+                ks = json.load(open(f))["kernels"]
+                hit = [v for k, v in ks.items() if f"gemv_reg_kernel<{wt}, 1280, 2, 2, {B}, 0, 2," in k]
+                if hit:
+                    traffic = round(hit[0]["hbm_bytes_per_launch"])
+                    break
+        except Exception:
+            traffic = None
         S_mid = P + n_codes // 2
         step_bytes = hp.gpt.step_bytes(B, S_mid)
         step_us = stage_ms["gpt_gen"] / args.steps * 1e3 / n_codes  # includes prefill + host syncs
         roofline = {
             "bound": "hbm", "kernel": f"gemv_reg_kernel<{args.dtype},K=1280,IN_LN,EPI_GELU> (decode LN2+FC, B={B})",
             "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-            "traffic": None, "bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3),
+            "traffic": traffic, "bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3),
             "decode_step": {"alg_bytes": step_bytes, "us": round(step_us, 1), "achieved_GBps": round(step_bytes / step_us / 1e3, 1),
                             "frac": round(step_bytes / step_us / 1e3 / 8000.0, 4), "kernels_per_step": 5 * L + 2},
         }
