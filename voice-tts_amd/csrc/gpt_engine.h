@@ -9,6 +9,7 @@
 namespace ixtts {
 
 constexpr int MAXB = 4;
+constexpr int STEPS_PER_GRAPH = 8;
 
 enum TKind { T_VEC = 0, T_MAT_T = 1, T_MAT_N = 2, T_EMB = 3 };
 
@@ -63,7 +64,8 @@ struct ixtts_gpt {
   float* scratch = nullptr;
   size_t scratch_floats = 0;
   hipStream_t cap_stream = nullptr;
-  hipGraphExec_t step_exec[ixtts::MAXB + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipGraphExec_t step_exec[ixtts::MAXB + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // 1 decode step
+  hipGraphExec_t multi_exec[ixtts::MAXB + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // STEPS_PER_GRAPH steps
   int host_prompt_len[ixtts::MAXB + 2];
   int host_gen_est[ixtts::MAXB + 2];
   // batched-rows workspace (prefill / latent): [max_seq][D] x4 + [max_seq][4D]
