@@ -84,6 +84,8 @@ static int gemv_out(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.nsplit = h->nsplit[B];
   if (a.nsplit > 1) {
     a.xin = h->part;
+    if (a.nsplit == 2) return launch_gemv<WT, KVT, D, DM::R1, DM::U_OUT, B, IN_ATTN2, EPI_RESID>(a, st);
+    if (a.nsplit == 4) return launch_gemv<WT, KVT, D, DM::R1, DM::U_OUT, B, IN_ATTN4, EPI_RESID>(a, st);
     return launch_gemv<WT, KVT, D, DM::R1, DM::U_OUT, B, IN_ATTN, EPI_RESID>(a, st);
   }
   a.xin = h->att;

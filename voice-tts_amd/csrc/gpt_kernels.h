@@ -24,7 +24,7 @@ namespace ixtts {
 
 constexpr int HD = 64;  // head dim (asserted at create)
 
-enum { IN_LN = 0, IN_LN2 = 1, IN_PLAIN = 2, IN_ATTN = 3 };
+enum { IN_LN = 0, IN_LN2 = 1, IN_PLAIN = 2, IN_ATTN = 3, IN_ATTN2 = 4, IN_ATTN4 = 5 };  // IN_ATTNn: split-S merge, n compile-time
 
 // split-S attention partials: per (slot, head, split) [m, l, pad, pad, acc[64]] (acc 16-byte aligned)
 constexpr int PART_STRIDE = 4 + 64;
@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(GemvArgs a) {
 
   // ---- 1. activation slice -> registers (L2-resident, issued first: vmcnt retires in order)
   float xr[B][NL][VEC];
-  if constexpr (INP == IN_ATTN) {
+  if constexpr (INP == IN_ATTN || INP == IN_ATTN2 || INP == IN_ATTN4) {
+    constexpr int NSP = INP == IN_ATTN2 ? 2 : (INP == IN_ATTN4 ? 4 : 0);  // 0: runtime a.nsplit
+    const int nsp = NSP ? NSP : a.nsplit;
     // flash-decode merge of the split-S partials, straight into the lane's slice:
     // x[k] = sum_s acc_s[k] e^{m_s - M} / sum_s l_s e^{m_s - M}
     constexpr int H = K / HD;
@@ -145,24 +147,52 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(GemvArgs a) {
       for (int j = 0; j < NL; ++j) {
         const int k0 = (j * PER + lane * VEC) % K;
         const int hh = k0 / HD, d0 = k0 % HD;
-        const float* p = a.xin + ((size_t)((a.slot0 + b) * H + hh) * a.nsplit) * PART_STRIDE;
-        float M = -INFINITY;
-        for (int sidx = 0; sidx < a.nsplit; ++sidx) M = fmaxf(M, p[sidx * PART_STRIDE]);
+        const float* p = a.xin + ((size_t)((a.slot0 + b) * H + hh) * nsp) * PART_STRIDE;
         float L = 0.f, o[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) o[v] = 0.f;
-        for (int sidx = 0; sidx < a.nsplit; ++sidx) {
-          const float* ps = p + sidx * PART_STRIDE;
-          const float2 ml = *reinterpret_cast<const float2*>(ps);
-          const float w = (ml.x > -INFINITY) ? expf(ml.x - M) : 0.f;
-          L = fmaf(ml.y, w, L);
+        if constexpr (NSP > 0) {
+          // all loads first (compile-time split count), then the merge
+          float2 ml[NSP];
+          float4 av[NSP][VEC / 4];
 #pragma unroll
-          for (int v4 = 0; v4 < VEC / 4; ++v4) {
-            const float4 t = *reinterpret_cast<const float4*>(ps + 4 + d0 + v4 * 4);
-            o[v4 * 4 + 0] = fmaf(t.x, w, o[v4 * 4 + 0]);
-            o[v4 * 4 + 1] = fmaf(t.y, w, o[v4 * 4 + 1]);
-            o[v4 * 4 + 2] = fmaf(t.z, w, o[v4 * 4 + 2]);
-            o[v4 * 4 + 3] = fmaf(t.w, w, o[v4 * 4 + 3]);
+          for (int sidx = 0; sidx < NSP; ++sidx) {
+            const float* ps = p + sidx * PART_STRIDE;
+            ml[sidx] = *reinterpret_cast<const float2*>(ps);
+#pragma unroll
+            for (int v4 = 0; v4 < VEC / 4; ++v4) av[sidx][v4] = *reinterpret_cast<const float4*>(ps + 4 + d0 + v4 * 4);
+          }
+          float M = -INFINITY;
+#pragma unroll
+          for (int sidx = 0; sidx < NSP; ++sidx) M = fmaxf(M, ml[sidx].x);
+#pragma unroll
+          for (int sidx = 0; sidx < NSP; ++sidx) {
+            const float w = (ml[sidx].x > -INFINITY) ? expf(ml[sidx].x - M) : 0.f;
+            L = fmaf(ml[sidx].y, w, L);
+#pragma unroll
+            for (int v4 = 0; v4 < VEC / 4; ++v4) {
+              o[v4 * 4 + 0] = fmaf(av[sidx][v4].x, w, o[v4 * 4 + 0]);
+              o[v4 * 4 + 1] = fmaf(av[sidx][v4].y, w, o[v4 * 4 + 1]);
+              o[v4 * 4 + 2] = fmaf(av[sidx][v4].z, w, o[v4 * 4 + 2]);
+              o[v4 * 4 + 3] = fmaf(av[sidx][v4].w, w, o[v4 * 4 + 3]);
+            }
+          }
+        } else {
+          float M = -INFINITY;
+          for (int sidx = 0; sidx < nsp; ++sidx) M = fmaxf(M, p[sidx * PART_STRIDE]);
+          for (int sidx = 0; sidx < nsp; ++sidx) {
+            const float* ps = p + sidx * PART_STRIDE;
+            const float2 ml = *reinterpret_cast<const float2*>(ps);
+            const float w = (ml.x > -INFINITY) ? expf(ml.x - M) : 0.f;
+            L = fmaf(ml.y, w, L);
+#pragma unroll
+            for (int v4 = 0; v4 < VEC / 4; ++v4) {
+              const float4 t = *reinterpret_cast<const float4*>(ps + 4 + d0 + v4 * 4);
+              o[v4 * 4 + 0] = fmaf(t.x, w, o[v4 * 4 + 0]);
+              o[v4 * 4 + 1] = fmaf(t.y, w, o[v4 * 4 + 1]);
+              o[v4 * 4 + 2] = fmaf(t.z, w, o[v4 * 4 + 2]);
+              o[v4 * 4 + 3] = fmaf(t.w, w, o[v4 * 4 + 3]);
+            }
           }
         }
         const float inv = 1.0f / L;
@@ -444,13 +474,20 @@ struct SoftAcc {
 // critical path; rows outside [p_lo, p_hi) are masked, addresses are clamped to the cache.
 template <typename KVT, int NW, int IT, typename BoundsFn>
 __device__ __forceinline__ void attn_sweep(SoftAcc<KVLayout<KVT>::DPL>& st, const KVT* kb, const KVT* vb,
-                                           const float (&qv)[KVLayout<KVT>::DPL], int smax, int wave, int lane, BoundsFn bounds) {
+                                           const float (&qv)[KVLayout<KVT>::DPL], int smax, int wave, int lane, BoundsFn bounds,
+                                           bool speculate = true) {
   using LY = KVLayout<KVT>;
   constexpr int DPL = LY::DPL, LPP = LY::LPP, PPW = LY::PPW;
   const int pg = lane / LPP;
   int p_lo = 0, p_hi = 0;
   bool have_bounds = false;
-  for (int base = 0;; base += NW * PPW * IT) {
+  int base0 = 0;
+  if (!speculate) {  // a split that does not start at row 0: fetch the bounds first and start at its own range
+    bounds(p_lo, p_hi);
+    have_bounds = true;
+    base0 = p_lo;
+  }
+  for (int base = base0;; base += NW * PPW * IT) {
     if (have_bounds && base >= p_hi) break;
     uint4 kr[IT], vr[IT];
 #pragma unroll
@@ -594,7 +631,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
       lo = vf + split * chunk;
       hi = min(S_end, lo + chunk);
     }
-  });
+  }, nsplit == 1);
   float M, L, O;
   const float o = attn_merge<KVT, NW>(st, sm, wave, lane, &M, &L, &O);
   if (threadIdx.x < 64) {
