@@ -245,3 +245,127 @@ def generate_greedy(oracle, embeds, mask, max_new, theta=10.0, stop_mel=8193, st
     if return_logits:
         return ids, margins, torch.stack(all_logits)
     return ids, margins
+
+
+# ------------------------------------------------------------------- beam-sample (G8, served default)
+class BeamHyps:
+    """BeamHypotheses (indextts/gpt/transformers_beam_search.py:930-1013), length_penalty / early_stopping=False."""
+
+    def __init__(self, num_beams, length_penalty=0.0):
+        self.num_beams = num_beams
+        self.length_penalty = length_penalty
+        self.beams = []  # (score, tokens)
+        self.worst_score = 1e9
+
+    def add(self, hyp, sum_logprobs, generated_len):
+        score = sum_logprobs / (generated_len ** self.length_penalty)
+        if len(self.beams) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, list(hyp)))
+            if len(self.beams) > self.num_beams:
+                order = sorted((s, i) for i, (s, _) in enumerate(self.beams))
+                del self.beams[order[0][1]]
+                self.worst_score = order[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs, cur_len, prompt_len):
+        if len(self.beams) < self.num_beams:
+            return False
+        highest = best_sum_logprobs / (cur_len - prompt_len) ** self.length_penalty
+        return self.worst_score >= highest
+
+
+def beam_process(hyps, done, histories, next_scores, next_tokens, next_indices, eos, prompt_len):
+    """BeamSearchScorer.process for one batch item (transformers_beam_search.py:215-318).
+
+    histories: list of per-beam generated-token lists; candidates sorted by score descending.
+    Returns (next_beam_scores, next_beam_tokens, next_beam_indices, done).
+    """
+    nb = hyps.num_beams
+    cur_len = prompt_len + len(histories[0]) + 1
+    if done:
+        return [0.0] * nb, [eos] * nb, [0] * nb, True
+    out_s, out_t, out_i = [], [], []
+    for rank, (tok, sc, bi) in enumerate(zip(next_tokens, next_scores, next_indices)):
+        if tok == eos:
+            if rank >= nb:
+                continue
+            hyps.add(histories[bi], sc, generated_len=cur_len - prompt_len)
+        else:
+            out_s.append(sc)
+            out_t.append(tok)
+            out_i.append(bi)
+        if len(out_s) == nb:
+            break
+    assert len(out_s) == nb, "fewer than num_beams non-eos candidates"
+    done = done or hyps.is_done(max(next_scores), cur_len, prompt_len)
+    return out_s, out_t, out_i, done
+
+
+def beam_finalize(hyps, done, histories, beam_scores, eos, max_new):
+    """BeamSearchScorer.finalize, num_return_sequences = 1 (transformers_beam_search.py:320-417)."""
+    if not done:
+        for b in range(hyps.num_beams):
+            hyps.add(histories[b], beam_scores[b], generated_len=len(histories[b]))
+    best = sorted(hyps.beams, key=lambda x: x[0])[-1]
+    seq = list(best[1])
+    if len(seq) < max_new:
+        seq.append(eos)
+    return seq, best[0]
+
+
+def beam_scores_step(logits_rows, histories_full, beam_scores, theta, temperature, top_k, top_p):
+    """log_softmax -> processors (min_tokens_to_keep = 2) -> + beam score (generation_utils.py:3473-3481)."""
+    rows = []
+    for b in range(len(beam_scores)):
+        lp = torch.log_softmax(logits_rows[b].to(torch.float32), dim=-1)
+        s = process_logits(lp, histories_full[b], theta, temperature, top_k, top_p, min_keep=2)
+        rows.append(s + beam_scores[b])
+    return torch.stack(rows)  # [num_beams, V]
+
+
+def generate_beam_sample(oracle, embeds, mask, max_new, num_beams=3, theta=10.0, temperature=0.8, top_k=30, top_p=0.8,
+                         stop_mel=8193, start_mel=8192, sampler=None, generator=None, trace=None):
+    """`_beam_search` with do_sample=True (generation_utils.py:3406-3565): the served default.
+
+    `sampler(scores_flat[num_beams*V]) -> 2*num_beams flat indices` lets a test force the draws;
+    default = softmax + torch.multinomial without replacement.
+    """
+    P = len(mask)
+    prefix = [1] * (P - 1) + [start_mel]
+    logits0, past0 = oracle.prefill(embeds, mask, start_mel)
+    V = logits0.numel()
+    logits = [logits0.clone() for _ in range(num_beams)]
+    pasts = [past0 for _ in range(num_beams)]
+    hist = [[] for _ in range(num_beams)]
+    beam_scores = [0.0] + [-1e9] * (num_beams - 1)
+    hyps, done = BeamHyps(num_beams), False
+    for step in range(1, max_new + 1):
+        scores = beam_scores_step(logits, [prefix + h for h in hist], beam_scores, theta, temperature, top_k, top_p)
+        flat = scores.reshape(-1)
+        if sampler is not None:
+            picks = sampler(flat, step)
+        else:
+            picks = torch.multinomial(torch.softmax(flat, -1), 2 * num_beams, generator=generator)
+        picks = torch.as_tensor(picks, dtype=torch.long)
+        sc = flat[picks]
+        sc, order = torch.sort(sc, descending=True)
+        picks = picks[order]
+        nidx = (picks // V).tolist()
+        ntok = (picks % V).tolist()
+        ns, nt, ni, done = beam_process(hyps, done, hist, sc.tolist(), ntok, nidx, stop_mel, P)
+        if trace is not None:
+            trace.append(dict(picks=picks.tolist(), scores=sc.tolist(), next_scores=list(ns), next_tokens=list(nt), next_indices=list(ni), done=done))
+        hist = [hist[ni[j]] + [nt[j]] for j in range(num_beams)]
+        beam_scores = list(ns)
+        pasts = [pasts[ni[j]] for j in range(num_beams)]
+        if done or step == max_new:
+            break
+        new_logits, new_pasts = [], []
+        for j in range(num_beams):
+            lg, pj = oracle.decode_step(nt[j], step, pasts[j], mask)
+            new_logits.append(lg)
+            new_pasts.append(pj)
+        logits, pasts = new_logits, new_pasts
+    seq, score = beam_finalize(hyps, done, hist, beam_scores, stop_mel, max_new)
+    return seq, score

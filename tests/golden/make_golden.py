@@ -198,6 +198,87 @@ def gen_gpt_block_prod():
          logits_first=logits[0], logits_last=logits[-1])
 
 
+def gen_beam():
+    out = {}
+    for tag, bias, seed in (("noeos", 14.0, 61), ("mid", 31.0, 64), ("mid2", 34.0, 65), ("eos", 38.0, 62), ("eos2", 42.0, 63)):
+        r = _gen_beam_case(bias, seed)
+        print(tag, "steps", r["picks"].shape[0], "done", int(r["done"]), "seq", r["sequence"].tolist())
+        out.update({f"{tag}_{k}": v for k, v in r.items()})
+    save("gpt_beam.npz", seed=31, **out)
+
+
+def _gen_beam_case(stop_bias, rng_seed):
+    """3-beam beam-sample through the reference's own BeamSearchScorer (vendored text,
+    transformers_beam_search.py:123-417) + HF processors + the reference model forward; draws come from a
+    seeded torch.multinomial and are stored so any implementation can replay them."""
+    from indextts.gpt.transformers_beam_search import BeamSearchScorer
+    from transformers.generation.logits_process import (
+        RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper)
+
+    cfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2)
+    W = WR.make_gpt_weights(cfg, seed=31, head_scale=50.0)
+    # make EOS reachable so hypotheses are produced: bias the stop token
+    W["mel_head.bias"] = W["mel_head.bias"].clone()
+    W["mel_head.bias"][8193] += stop_bias
+    uv = build_ref_gpt(cfg, W)
+    g = torch.Generator().manual_seed(rng_seed)
+    D = cfg["model_dim"]
+    conds_latent = torch.randn(34, D, generator=g) * 0.5
+    text = torch.randint(2, 200, (10,), generator=g).to(torch.int32)
+    nb, V, max_new = 3, 8194, 24
+    input_ids, embeds, mask = uv.prepare_gpt_inputs(conds_latent.unsqueeze(0), text.unsqueeze(0))
+    P = input_ids.shape[1]
+    model = uv.inference_model
+    model.store_mel_emb(embeds)
+    procs = [RepetitionPenaltyLogitsProcessor(10.0), TemperatureLogitsWarper(0.8), TopKLogitsWarper(30, min_tokens_to_keep=2),
+             TopPLogitsWarper(0.8, min_tokens_to_keep=2)]
+    scorer = BeamSearchScorer(batch_size=1, num_beams=nb, device="cpu", length_penalty=0.0, do_early_stopping=False,
+                              num_beam_hyps_to_keep=1, max_length=P + max_new)
+    input_ids = input_ids.repeat_interleave(nb, dim=0)
+    mask = mask.repeat_interleave(nb, dim=0)
+    beam_scores = torch.zeros(nb)
+    beam_scores[1:] = -1e9
+    past = None
+    all_picks, all_ns, all_nt, all_ni = [], [], [], []
+    next_tokens = next_indices = None
+    for step in range(max_new):
+        inp = model.prepare_inputs_for_generation(input_ids, past_key_values=past, attention_mask=mask, use_cache=True)
+        out = model(**inp, return_dict=True)
+        past = out.past_key_values
+        scores = torch.log_softmax(out.logits[:, -1, :].float(), dim=-1)
+        for pr in procs:
+            scores = pr(input_ids, scores)
+        scores = scores + beam_scores[:, None]
+        flat = scores.view(1, nb * V)
+        picks = torch.multinomial(torch.softmax(flat, -1), 2 * nb, generator=g)
+        sc = torch.gather(flat, -1, picks)
+        sc, order = torch.sort(sc, descending=True, dim=1)
+        picks = torch.gather(picks, -1, order)
+        next_indices = torch.div(picks, V, rounding_mode="floor")
+        next_tokens = picks % V
+        bo = scorer.process(input_ids, sc, next_tokens, next_indices, pad_token_id=8193, eos_token_id=8193, decoder_prompt_len=P)
+        beam_scores = bo["next_beam_scores"]
+        bt, bi = bo["next_beam_tokens"], bo["next_beam_indices"]
+        all_picks.append(picks[0].clone())
+        all_ns.append(beam_scores.clone())
+        all_nt.append(bt.clone())
+        all_ni.append(bi.clone())
+        input_ids = torch.cat([input_ids[bi, :], bt.unsqueeze(-1)], dim=-1)
+        mask = torch.cat([mask, torch.ones(nb, 1, dtype=mask.dtype)], dim=1)
+        if hasattr(past, "reorder_cache"):
+            past.reorder_cache(bi)
+        else:
+            past = model._reorder_cache(past, bi)
+        if scorer.is_done:
+            break
+    fin = scorer.finalize(input_ids, beam_scores, next_tokens, next_indices, pad_token_id=8193, eos_token_id=8193,
+                          max_length=P + max_new, decoder_prompt_len=P)
+    seq = fin["sequences"][0, P:]
+    return dict(stop_bias=stop_bias, conds_latent=conds_latent, text=text, max_new=max_new, picks=torch.stack(all_picks),
+                next_scores=torch.stack(all_ns), next_tokens=torch.stack(all_nt), next_indices=torch.stack(all_ni),
+                sequence=seq, sequence_score=fin["sequence_scores"], done=int(bool(scorer.is_done)))
+
+
 # ----------------------------------------------------------------------------- G8
 def gen_sampler():
     from transformers.generation.logits_process import (
@@ -223,7 +304,7 @@ def gen_sampler():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["aa", "bigvgan", "gpt", "prod", "sampler"]
+    which = sys.argv[1:] or ["aa", "bigvgan", "gpt", "prod", "sampler", "beam"]
     if "aa" in which:
         gen_aa_snake()
     if "bigvgan" in which:
@@ -234,3 +315,5 @@ if __name__ == "__main__":
         gen_gpt_block_prod()
     if "sampler" in which:
         gen_sampler()
+    if "beam" in which:
+        gen_beam()

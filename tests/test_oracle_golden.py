@@ -132,3 +132,27 @@ def test_sampler_processors_vs_hf(golden, case, min_keep):
     assert torch.allclose(fin[keep], ref[keep], atol=1e-6)
     assert torch.allclose(torch.softmax(fin, -1), torch.from_numpy(g[f"{case}_probs"]), atol=1e-6)
     assert int(keep.sum()) >= min_keep
+
+
+@pytest.mark.parametrize("tag", ["noeos", "mid", "mid2", "eos", "eos2"])
+def test_beam_sample_vs_reference_scorer(golden, tag):
+    """3-beam beam-sample (the served default): oracle loop + scorer restatement vs a trace produced by
+    the reference's own BeamSearchScorer / HF processors / model forward, replaying the recorded draws."""
+    g = golden("gpt_beam.npz")
+    cfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2)
+    W = WR.make_gpt_weights(cfg, seed=int(g["seed"]), head_scale=50.0)
+    W["mel_head.bias"] = W["mel_head.bias"].clone()
+    W["mel_head.bias"][8193] += float(g[f"{tag}_stop_bias"])
+    orc = OG.GptOracle(W, cfg["layers"], cfg["heads"])
+    fake, embeds, mask = orc.prepare_gpt_inputs(torch.from_numpy(g[f"{tag}_conds_latent"]), g[f"{tag}_text"])
+    picks = g[f"{tag}_picks"]
+    trace = []
+    seq, score = OG.generate_beam_sample(orc, embeds, mask, int(g[f"{tag}_max_new"]), num_beams=3,
+                                         sampler=lambda flat, step: picks[step - 1], trace=trace)
+    assert len(trace) == picks.shape[0]
+    for t, ns, nt, ni in zip(trace, g[f"{tag}_next_scores"], g[f"{tag}_next_tokens"], g[f"{tag}_next_indices"]):
+        assert t["next_tokens"] == nt.tolist() and t["next_indices"] == ni.tolist()
+        assert np.allclose(t["next_scores"], ns, rtol=1e-4, atol=1e-3)
+    assert trace[-1]["done"] == bool(g[f"{tag}_done"])
+    assert seq == g[f"{tag}_sequence"].tolist()
+    assert abs(score - float(g[f"{tag}_sequence_score"][0])) <= 1e-3 * max(1.0, abs(score))
