@@ -161,6 +161,21 @@ int ixtts_gpt_read_probs(ixtts_gpt* h, int b, float* probs_host, void* stream);
 /* Teacher forcing for parity tests: overrides the NEXT token chosen for slot b. */
 int ixtts_gpt_force_next(ixtts_gpt* h, int b, int32_t token, void* stream);
 
+/* Beam-sample, the reference's served default (`num_beams=3, do_sample=True`: infer_v2.py:598-605) --
+ * `_beam_search` + `BeamSearchScorer` (transformers_generation_utils.py:3406-3565, transformers_beam_search.py:215-417,
+ * 930-1013) with the whole per-step bookkeeping on the device.  Usage: ixtts_gpt_prefill(h, 0, ...) ->
+ * ixtts_gpt_beam_begin(h, num_beams) (beams take slots 0..num_beams-1, needs max_batch >= num_beams) ->
+ * ixtts_gpt_beam_decode(h, n_steps, cfg) as often as needed -> ixtts_gpt_beam_read. */
+int ixtts_gpt_beam_begin(ixtts_gpt* h, int num_beams, void* stream);
+int ixtts_gpt_beam_decode(ixtts_gpt* h, int n_steps, const ixtts_sampler_cfg* sc, void* stream);
+/* Synchronises; runs `finalize` (best hypothesis, + eos if it fits in max_new) and returns it.  `done` = the scorer's
+ * is_done flag.  Optional outputs (may be NULL): best score, and for tests the open beams' scores [num_beams], their
+ * last tokens and the beam_idx of the last step. */
+int ixtts_gpt_beam_read(ixtts_gpt* h, int max_new, int32_t* ids_host, int cap, int* n_ids, int* done, float* score,
+                        float* beam_scores_host, int32_t* last_tokens_host, int32_t* beam_idx_host, void* stream);
+/* Parity-test hook: the NEXT beam step uses these 2*num_beams flat draws (beam*V + token) instead of sampling. */
+int ixtts_gpt_beam_force(ixtts_gpt* h, const int32_t* picks_host, int n, void* stream);
+
 /* `UnifiedVoice.forward(...)->get_logits(return_latent=True)` (model_v2.py:554-596,486-512):
  * prefix_dev [n_prefix, D] = [conds 34 ; text_emb L+2] rows; codes_dev [n] int32 mel codes.
  * Embeds [start, codes, stop] with mel positions 0..n+1, runs the full causal trunk,

@@ -74,7 +74,7 @@ def test_generate_surface_matches_reference_call(tiny_f32, dev):
     assert out[0, :P].tolist() == fake[0].tolist()
     assert out[0, P:].tolist() == g["ids_padded"].tolist()
     with pytest.raises(NotImplementedError):
-        eng.generate(fake, attention_mask=mask, max_length=P + 4, num_beams=3)
+        eng.generate(fake, attention_mask=mask, max_length=P + 4, num_beams=3)  # this engine was built with max_batch=2
     # sampling through the same surface (served defaults except num_beams): ids stay in range, length honoured
     out2 = eng.generate(fake, attention_mask=mask, max_length=P + 12, do_sample=True, top_p=0.8, top_k=30, temperature=0.8,
                         num_beams=1, repetition_penalty=10.0, seed=7)
@@ -245,3 +245,83 @@ def test_errors(tiny_f32, dev):
         e2.load_state_dict({k: v for k, v in W.items() if k != "final_norm.bias"})  # finalize reports the gap
     with pytest.raises(IxttsError):
         e2.decode(1, 1)  # not finalized
+
+
+@pytest.fixture(scope="module")
+def beam_engines(golden, dev):
+    """One fp32 engine per stop-token bias used by the beam fixtures (max_batch 3 = the served num_beams)."""
+    import voice_tts_amd.weights as WR
+    from oracle import gpt as OG
+    from voice_tts_amd.gpt_engine import GptEngine
+
+    g = golden("gpt_beam.npz")
+    cfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2)
+    out = {}
+    for tag in ("noeos", "mid", "mid2", "eos", "eos2"):
+        W = WR.make_gpt_weights(cfg, seed=int(g["seed"]), head_scale=50.0)
+        W["mel_head.bias"] = W["mel_head.bias"].clone()
+        W["mel_head.bias"][8193] += float(g[f"{tag}_stop_bias"])
+        orc = OG.GptOracle(W, cfg["layers"], cfg["heads"])
+        eng = GptEngine(cfg, dtype="f32", max_seq=128, max_batch=3, device=dev).load_state_dict(W)
+        out[tag] = (orc, eng)
+    return g, out
+
+
+@pytest.mark.parametrize("tag", ["noeos", "mid", "mid2", "eos", "eos2"])
+def test_beam_sample_replays_reference_trace(beam_engines, tag):
+    """Served default (num_beams=3, do_sample): device processors + BeamSearchScorer bookkeeping + KV reorder,
+    replaying the draws recorded from the reference's own scorer run (tests/golden/gpt_beam.npz)."""
+    g, engines = beam_engines
+    orc, eng = engines[tag]
+    fake, embeds, mask = orc.prepare_gpt_inputs(torch.from_numpy(g[f"{tag}_conds_latent"]), g[f"{tag}_text"])
+    picks = g[f"{tag}_picks"]
+    max_new = int(g[f"{tag}_max_new"])
+    eng.prefill(0, embeds, 0)
+    eng.beam_begin(3)
+    for step in range(picks.shape[0]):
+        eng.beam_force(picks[step])
+        eng.beam_decode(1, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8)
+        ids, done, score, bs, lt, src = eng.beam_read(max_new)
+        assert lt.tolist() == g[f"{tag}_next_tokens"][step].tolist(), step
+        assert src.tolist() == g[f"{tag}_next_indices"][step].tolist(), step
+        assert np.allclose(bs, g[f"{tag}_next_scores"][step], rtol=1e-4, atol=2e-3), step
+    assert done == bool(g[f"{tag}_done"])
+    assert ids.tolist() == g[f"{tag}_sequence"].tolist()
+    assert abs(score - float(g[f"{tag}_sequence_score"][0])) <= 2e-3 * max(1.0, abs(score))
+    # once done, further steps change nothing (HF leaves the loop)
+    if done:
+        eng.beam_decode(3, repetition_penalty=10.0)
+        ids2, done2 = eng.beam_read(max_new)[:2]
+        assert done2 and ids2.tolist() == ids.tolist()
+
+
+def test_beam_sample_free_running_and_generate_surface(beam_engines, dev):
+    from oracle import gpt as OG
+
+    g, engines = beam_engines
+    orc, eng = engines["noeos"]
+    fake, embeds, mask = orc.prepare_gpt_inputs(torch.from_numpy(g["noeos_conds_latent"]), g["noeos_text"])
+    P = len(mask)
+    # step 1: beam_scores = [0,-1e9,-1e9] -> the three new beams are distinct tokens of beam 0's filtered support
+    logits0, _ = orc.prefill(embeds, mask)
+    support = OG.process_logits(torch.log_softmax(logits0, -1), [1] * (P - 1) + [8192], 10.0, 0.8, 30, 0.8, min_keep=2)
+    allowed = set(torch.nonzero(~torch.isinf(support)).flatten().tolist())
+    firsts = set()
+    for seed in range(12):
+        eng.prefill(0, embeds, 0)
+        eng.beam_begin(3)
+        eng.beam_decode(1, seed=seed)
+        ids, done, score, bs, lt, src = eng.beam_read(24)
+        assert src.tolist() == [0, 0, 0] or not (bs > -1e8).all()
+        live = [int(t) for t, s in zip(lt, bs) if s > -1e8]
+        assert len(set(live)) == len(live) and set(live) <= allowed
+        firsts.update(live)
+    assert len(firsts) > 1
+    # the reference-shaped call with the served defaults (model_v2.py:724-729, infer_v2.py:598-606)
+    eng.store_mel_emb(embeds.unsqueeze(0).to(dev))
+    fk = torch.ones(1, P, dtype=torch.long, device=dev)
+    fk[0, -1] = 8192
+    out = eng.generate(fk, bos_token_id=8192, pad_token_id=8193, eos_token_id=8193, attention_mask=mask.unsqueeze(0).to(dev),
+                       max_length=P + 20, num_return_sequences=1, do_sample=True, top_p=0.8, top_k=30, temperature=0.8,
+                       num_beams=3, repetition_penalty=10.0, length_penalty=0.0, seed=3)
+    assert out.shape[0] == 1 and P < out.shape[1] <= P + 20 and int(out[0, P:].max()) < 8194

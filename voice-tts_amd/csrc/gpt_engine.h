@@ -68,6 +68,13 @@ struct ixtts_gpt {
   hipGraphExec_t multi_exec[ixtts::MAXB + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // STEPS_PER_GRAPH steps
   int host_prompt_len[ixtts::MAXB + 2];
   int host_gen_est[ixtts::MAXB + 2];
+  // beam-sample state (gpt_beam.hip): beams occupy slots 0..num_beams-1
+  int num_beams = 0;
+  float *beam_scores = nullptr, *hyp_score = nullptr, *hyp_worst = nullptr;
+  int *beam_src = nullptr, *hyp_len = nullptr, *n_hyp = nullptr, *beam_done = nullptr, *beam_forced_flag = nullptr;
+  int32_t *hyp_tok = nullptr, *beam_forced = nullptr;
+  hipGraphExec_t beam_exec = nullptr, beam_multi_exec = nullptr;
+  int beam_exec_nb = 0;
   // batched-rows workspace (prefill / latent): [max_seq][D] x4 + [max_seq][4D]
   float *rx = nullptr, *rxn = nullptr, *rq = nullptr, *ratt = nullptr, *rff = nullptr;
 };
@@ -86,4 +93,6 @@ int forward_rows(ixtts_gpt* h, int slot, int T, int pos0, int valid_from, hipStr
 namespace ixtts {
 int final_norm_rows(ixtts_gpt* h, const float* x, float* y, int T, hipStream_t st);
 int embed_mel_rows(ixtts_gpt* h, float* x, const int32_t* codes, int rows, hipStream_t st);
+struct SamplerState;
+void launch_beam_step(ixtts_gpt* h, const SamplerState& s, hipStream_t st);
 }  // namespace ixtts

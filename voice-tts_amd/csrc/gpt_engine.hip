@@ -171,7 +171,7 @@ static int forward_layers(ixtts_gpt* h, int slot0, hipStream_t st) {
   return IXTTS_OK;
 }
 
-static void launch_sampler(ixtts_gpt* h, int n_active, hipStream_t st) {
+static SamplerState make_sampler_state(ixtts_gpt* h) {
   SamplerState s;
   s.logits = h->logits;
   s.seen = h->seen;
@@ -192,6 +192,11 @@ static void launch_sampler(ixtts_gpt* h, int n_active, hipStream_t st) {
   s.stop = h->cfg.stop_mel_token;
   s.slot0 = 0;
   s.probs_out = h->probs;
+  return s;
+}
+
+static void launch_sampler(ixtts_gpt* h, int n_active, hipStream_t st) {
+  SamplerState s = make_sampler_state(h);
   hipLaunchKernelGGL(sampler_kernel, dim3(n_active), dim3(1024), 0, st, s);
 }
 
@@ -331,6 +336,16 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   ok &= hipMalloc(&h->tokens, (size_t)S * h->smax * 4) == hipSuccess;
   ok &= hipMalloc(&h->seen, (size_t)S * V) == hipSuccess;
   ok &= hipMalloc(&h->d_samp, sizeof(ixtts_sampler_cfg)) == hipSuccess;
+  ok &= hipMalloc(&h->beam_scores, MAXB * 4) == hipSuccess;
+  ok &= hipMalloc(&h->hyp_score, MAXB * 4) == hipSuccess;
+  ok &= hipMalloc(&h->hyp_worst, 4) == hipSuccess;
+  ok &= hipMalloc(&h->beam_src, MAXB * 4) == hipSuccess;
+  ok &= hipMalloc(&h->hyp_len, MAXB * 4) == hipSuccess;
+  ok &= hipMalloc(&h->n_hyp, 4) == hipSuccess;
+  ok &= hipMalloc(&h->beam_done, 4) == hipSuccess;
+  ok &= hipMalloc(&h->beam_forced_flag, 4) == hipSuccess;
+  ok &= hipMalloc(&h->beam_forced, 2 * MAXB * 4) == hipSuccess;
+  ok &= hipMalloc(&h->hyp_tok, (size_t)MAXB * h->smax * 4) == hipSuccess;
   ok &= hipMalloc(&h->probs, (size_t)S * V * 4) == hipSuccess;
   h->scratch_floats = (size_t)FF * D;
   ok &= hipMalloc(&h->scratch, h->scratch_floats * 4) == hipSuccess;
@@ -508,13 +523,14 @@ extern "C" int ixtts_gpt_prefill(ixtts_gpt* h, int b, const float* embeds, int n
 // ------------------------------------------------------------------------------------ decode
 // One graph = `reps` consecutive decode steps (sampler -> 24 layers -> head, 122 kernels each): replaying an
 // 8-step graph amortises the ~10-16 us host cost of a graph launch over 8 tokens.
-static int build_step_graph(ixtts_gpt* h, int B, int reps, hipGraphExec_t* out) {
+static int build_step_graph(ixtts_gpt* h, int B, int reps, hipGraphExec_t* out, bool beam = false) {
   hipGraph_t g;
   hipStream_t cs = h->cap_stream;
   IX_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
   int rc = IXTTS_OK;
   for (int r = 0; r < reps && rc == IXTTS_OK; ++r) {
-    launch_sampler(h, B, cs);
+    if (beam) launch_beam_step(h, make_sampler_state(h), cs);
+    else launch_sampler(h, B, cs);
     rc = do_forward_layers(h, B, 0, cs);
     if (rc == IXTTS_OK) rc = do_head(h, B, 0, nullptr, cs);
   }
@@ -551,6 +567,151 @@ extern "C" int ixtts_gpt_decode(ixtts_gpt* h, int n_active, int n_steps, const i
   for (; left >= STEPS_PER_GRAPH; left -= STEPS_PER_GRAPH) IX_HIP(hipGraphLaunch(h->multi_exec[n_active], st));
   for (; left > 0; --left) IX_HIP(hipGraphLaunch(h->step_exec[n_active], st));
   for (int b = 0; b < n_active; ++b) h->host_gen_est[b] += n_steps;
+  return IXTTS_OK;
+}
+
+// ------------------------------------------------------------------------------------ beam-sample
+extern "C" int ixtts_gpt_beam_begin(ixtts_gpt* h, int num_beams, void* stream) {
+  NEED_READY(h, "gpt_beam_begin");
+  IX_ARG(num_beams >= 2 && num_beams <= h->cfg.max_batch && num_beams <= MAXB, "gpt_beam_begin: num_beams %d needs max_batch >= it (<= %d)", num_beams, MAXB);
+  IX_ARG(h->host_prompt_len[0] > 0, "gpt_beam_begin: slot 0 has no prefilled prompt");
+  hipStream_t st = (hipStream_t)stream;
+  const int D = h->D, V = h->V;
+  const size_t slot_bytes = (size_t)D * h->smax * h->esize;
+  const size_t layer_bytes = (size_t)h->slots * slot_bytes;
+  // input_ids.repeat_interleave(num_beams): every beam starts as a copy of the prefilled sequence
+  for (int b = 1; b < num_beams; ++b) {
+    for (int l = 0; l < h->L; ++l) {
+      IX_HIP(hipMemcpyAsync((char*)h->kc + l * layer_bytes + b * slot_bytes, (char*)h->kc + l * layer_bytes, slot_bytes, hipMemcpyDeviceToDevice, st));
+      IX_HIP(hipMemcpyAsync((char*)h->vc + l * layer_bytes + b * slot_bytes, (char*)h->vc + l * layer_bytes, slot_bytes, hipMemcpyDeviceToDevice, st));
+    }
+    IX_HIP(hipMemcpyAsync(h->logits + (size_t)b * V, h->logits, (size_t)V * 4, hipMemcpyDeviceToDevice, st));
+    IX_HIP(hipMemcpyAsync(h->seen + (size_t)b * V, h->seen, V, hipMemcpyDeviceToDevice, st));
+    IX_HIP(hipMemcpyAsync(h->prompt_len + b, h->prompt_len, 4, hipMemcpyDeviceToDevice, st));
+    IX_HIP(hipMemcpyAsync(h->valid_from + b, h->valid_from, 4, hipMemcpyDeviceToDevice, st));
+    IX_HIP(hipMemcpyAsync(h->gen_count + b, h->gen_count, 4, hipMemcpyDeviceToDevice, st));
+    IX_HIP(hipMemcpyAsync(h->finished + b, h->finished, 4, hipMemcpyDeviceToDevice, st));
+    h->host_prompt_len[b] = h->host_prompt_len[0];
+    h->host_gen_est[b] = h->host_gen_est[0];
+  }
+  // beam_scores = [0, -1e9, ...] so only beam 0's tokens can be drawn at the first step (generation_utils.py:3406-3410)
+  float bs[MAXB];
+  for (int b = 0; b < MAXB; ++b) bs[b] = b == 0 ? 0.f : -1e9f;
+  IX_HIP(hipMemcpyAsync(h->beam_scores, bs, num_beams * 4, hipMemcpyHostToDevice, st));
+  const float worst = 1e9f;
+  IX_HIP(hipMemcpyAsync(h->hyp_worst, &worst, 4, hipMemcpyHostToDevice, st));
+  IX_HIP(hipMemsetAsync(h->n_hyp, 0, 4, st));
+  IX_HIP(hipMemsetAsync(h->beam_done, 0, 4, st));
+  IX_HIP(hipMemsetAsync(h->beam_forced_flag, 0, 4, st));
+  IX_HIP(hipStreamSynchronize(st));  // bs / worst are stack variables
+  h->num_beams = num_beams;
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_gpt_beam_force(ixtts_gpt* h, const int32_t* picks, int n, void* stream) {
+  NEED_READY(h, "gpt_beam_force");
+  IX_ARG(h->num_beams >= 2 && picks && n == 2 * h->num_beams, "gpt_beam_force: need 2*num_beams picks after beam_begin");
+  hipStream_t st = (hipStream_t)stream;
+  const int one = 1;
+  IX_HIP(hipMemcpyAsync(h->beam_forced, picks, n * 4, hipMemcpyHostToDevice, st));
+  IX_HIP(hipMemcpyAsync(h->beam_forced_flag, &one, 4, hipMemcpyHostToDevice, st));
+  IX_HIP(hipStreamSynchronize(st));
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_gpt_beam_decode(ixtts_gpt* h, int n_steps, const ixtts_sampler_cfg* sc, void* stream) {
+  NEED_READY(h, "gpt_beam_decode");
+  IX_ARG(sc && n_steps >= 0, "gpt_beam_decode: bad argument");
+  IX_ARG(h->num_beams >= 2, "gpt_beam_decode: call gpt_beam_begin first");
+  IX_ARG(sc->top_k >= 1 && sc->top_k <= SAMP_MAXK && sc->temperature > 0.f && sc->top_p > 0.f, "gpt_beam_decode: 1 <= top_k <= %d, positive temperature/top_p", SAMP_MAXK);
+  IX_ARG(h->V <= 1024 * SAMP_PT, "gpt_beam_decode: vocabulary %d exceeds the sampler tile", h->V);
+  const int nb = h->num_beams;
+  IX_ARG(h->host_prompt_len[0] + h->host_gen_est[0] + n_steps < h->smax, "gpt_beam_decode: would overflow max_seq %d", h->smax);
+  hipStream_t st = (hipStream_t)stream;
+  if (!h->beam_exec || h->beam_exec_nb != nb) {
+    if (h->beam_exec) hipGraphExecDestroy(h->beam_exec);
+    if (h->beam_multi_exec) hipGraphExecDestroy(h->beam_multi_exec);
+    h->beam_exec = h->beam_multi_exec = nullptr;
+    IX_TRY(build_step_graph(h, nb, 1, &h->beam_exec, true));
+    IX_TRY(build_step_graph(h, nb, STEPS_PER_GRAPH, &h->beam_multi_exec, true));
+    h->beam_exec_nb = nb;
+  }
+  h->samp_host = *sc;
+  IX_HIP(hipMemcpyAsync(h->d_samp, &h->samp_host, sizeof(ixtts_sampler_cfg), hipMemcpyHostToDevice, st));
+  int left = n_steps;
+  for (; left >= STEPS_PER_GRAPH; left -= STEPS_PER_GRAPH) IX_HIP(hipGraphLaunch(h->beam_multi_exec, st));
+  for (; left > 0; --left) IX_HIP(hipGraphLaunch(h->beam_exec, st));
+  for (int b = 0; b < nb; ++b) h->host_gen_est[b] += n_steps;
+  return IXTTS_OK;
+}
+
+// BeamSearchScorer.finalize (transformers_beam_search.py:320-417), num_return_sequences = 1, on the host.
+extern "C" int ixtts_gpt_beam_read(ixtts_gpt* h, int max_new, int32_t* ids, int cap, int* n_ids, int* done, float* score,
+                                   float* beam_scores_out, int32_t* last_tokens_out, int32_t* src_out, void* stream) {
+  NEED_READY(h, "gpt_beam_read");
+  IX_ARG(h->num_beams >= 2 && ids && n_ids && done && cap >= 0 && max_new >= 0, "gpt_beam_read: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  IX_HIP(hipStreamSynchronize(st));
+  const int nb = h->num_beams;
+  int gc = 0, dn = 0, nh = 0;
+  float bs[MAXB], hs[MAXB];
+  int hl[MAXB], src[MAXB];
+  IX_HIP(hipMemcpy(&gc, h->gen_count, 4, hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(&dn, h->beam_done, 4, hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(&nh, h->n_hyp, 4, hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(bs, h->beam_scores, nb * 4, hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(hs, h->hyp_score, nb * 4, hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(hl, h->hyp_len, nb * 4, hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(src, h->beam_src, nb * 4, hipMemcpyDeviceToHost));
+  gc = std::min(gc, h->smax);
+  std::vector<std::vector<int32_t>> open(nb), hyp(nh);
+  for (int b = 0; b < nb; ++b) {
+    open[b].resize(gc);
+    if (gc) IX_HIP(hipMemcpy(open[b].data(), h->tokens + (size_t)b * h->smax, (size_t)gc * 4, hipMemcpyDeviceToHost));
+  }
+  for (int i = 0; i < nh; ++i) {
+    hyp[i].resize(hl[i]);
+    if (hl[i]) IX_HIP(hipMemcpy(hyp[i].data(), h->hyp_tok + (size_t)i * h->smax, (size_t)hl[i] * 4, hipMemcpyDeviceToHost));
+  }
+  if (beam_scores_out) memcpy(beam_scores_out, bs, nb * 4);
+  if (src_out) memcpy(src_out, src, nb * 4);
+  if (last_tokens_out)
+    for (int b = 0; b < nb; ++b) last_tokens_out[b] = gc ? open[b][gc - 1] : -1;
+  // candidates: finished hypotheses, plus (if not done) the open beams through BeamHypotheses.add
+  std::vector<std::pair<float, std::vector<int32_t>>> beams;
+  for (int i = 0; i < nh; ++i) beams.emplace_back(hs[i], hyp[i]);
+  float worst = 1e9f;
+  for (auto& bsc : beams) worst = std::min(worst, bsc.first);
+  if (!dn) {
+    for (int b = 0; b < nb; ++b) {
+      const float sc = bs[b];
+      if ((int)beams.size() < nb || sc > worst) {
+        beams.emplace_back(sc, open[b]);
+        if ((int)beams.size() > nb) {
+          int wi = 0;
+          for (int i = 1; i < (int)beams.size(); ++i)
+            if (beams[i].first < beams[wi].first) wi = i;
+          beams.erase(beams.begin() + wi);
+          worst = 1e9f;
+          for (auto& bb : beams) worst = std::min(worst, bb.first);
+        } else {
+          worst = std::min(sc, worst);
+        }
+      }
+    }
+  }
+  IX_ARG(!beams.empty(), "gpt_beam_read: no hypothesis available");
+  // sorted(key=score).pop(): the LAST of the maximal scores in insertion order
+  int bi = 0;
+  for (int i = 1; i < (int)beams.size(); ++i)
+    if (beams[i].first >= beams[bi].first) bi = i;
+  std::vector<int32_t> seq = beams[bi].second;
+  if ((int)seq.size() < max_new) seq.push_back(h->cfg.stop_mel_token);
+  const int n = std::min((int)seq.size(), cap);
+  for (int i = 0; i < n; ++i) ids[i] = seq[i];
+  *n_ids = n;
+  *done = dn;
+  if (score) *score = beams[bi].first;
   return IXTTS_OK;
 }
 
@@ -646,9 +807,12 @@ extern "C" int ixtts_gpt_destroy(ixtts_gpt* h) {
     if (h->step_exec[b]) hipGraphExecDestroy(h->step_exec[b]);
     if (h->multi_exec[b]) hipGraphExecDestroy(h->multi_exec[b]);
   }
+  if (h->beam_exec) hipGraphExecDestroy(h->beam_exec);
+  if (h->beam_multi_exec) hipGraphExecDestroy(h->beam_multi_exec);
   if (h->cap_stream) hipStreamDestroy(h->cap_stream);
   void* ptrs[] = {h->arena, h->stage, h->kc, h->vc, h->h, h->q, h->ff, h->att, h->part, h->logits, h->rowbuf, h->cur_len, h->gen_count,
-                  h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->probs, h->scratch,
+                  h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->probs, h->scratch, h->beam_scores, h->hyp_score, h->hyp_worst, h->beam_src, h->hyp_len,
+                  h->n_hyp, h->beam_done, h->beam_forced_flag, h->beam_forced, h->hyp_tok,
                   h->rx, h->rxn, h->rq, h->ratt, h->rff};
   for (void* p : ptrs)
     if (p) hipFree(p);

@@ -649,7 +649,6 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
   }
 }
 
-#ifdef IXTTS_ENGINE_TU  // non-template kernels: compiled into gpt_engine.hip only
 // ------------------------------------------------------------------------------------
 // Sampler + embed (rows G8, G1).  One workgroup of 1024 threads per slot.
 struct SamplerState {
@@ -686,6 +685,8 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned int
 
 constexpr int SAMP_MAXK = 128;  // top_k supported on the device
 constexpr int SAMP_PT = 9;      // logits per thread (V <= 9216)
+
+#ifdef IXTTS_ENGINE_TU  // non-template kernels: compiled into gpt_engine.hip only
 
 // Processor chain in `_get_logits_processor` order (generation_utils.py:900-901,1020-1044):
 // [suppress] -> RepetitionPenalty -> Temperature -> TopK (ties with the k-th value kept) -> TopP -> softmax ->

@@ -116,6 +116,34 @@ class GptEngine:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().ixtts_gpt_force_next(self._h, slot, int(token), self._stream()), "ixtts_gpt_force_next")
 
+    # ------------------------------------------------------------------ beam-sample
+    def beam_begin(self, num_beams):
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ixtts_gpt_beam_begin(self._h, int(num_beams), self._stream()), "ixtts_gpt_beam_begin")
+        self._nb = int(num_beams)
+
+    def beam_decode(self, n_steps, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=False, seed=0):
+        sc = _lib.SamplerCfg(repetition_penalty, temperature, top_k, top_p, 1, int(suppress_stop), seed)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ixtts_gpt_beam_decode(self._h, n_steps, C.byref(sc), self._stream()), "ixtts_gpt_beam_decode")
+
+    def beam_force(self, picks):
+        a = np.ascontiguousarray(np.asarray(picks, dtype=np.int32))
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ixtts_gpt_beam_force(self._h, a.ctypes.data, a.size, self._stream()), "ixtts_gpt_beam_force")
+
+    def beam_read(self, max_new):
+        ids = np.zeros(self.max_seq + 1, dtype=np.int32)
+        n, done, score = C.c_int(), C.c_int(), C.c_float()
+        bs = np.zeros(self._nb, np.float32)
+        lt = np.zeros(self._nb, np.int32)
+        src = np.zeros(self._nb, np.int32)
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().ixtts_gpt_beam_read(self._h, int(max_new), ids.ctypes.data, ids.size, C.byref(n), C.byref(done), C.byref(score),
+                                                bs.ctypes.data, lt.ctypes.data, src.ctypes.data, self._stream())
+        _lib.check(rc, "ixtts_gpt_beam_read")
+        return ids[: n.value].copy(), bool(done.value), float(score.value), bs, lt, src
+
     def latent(self, prefix, codes):
         """prefix [34+L+2, D] fp32 (conds ; text_emb); codes int [n] -> latent [n, D] (model_v2.py:554-596)."""
         p = prefix.to(self.device, torch.float32).contiguous()
@@ -151,8 +179,8 @@ class GptEngine:
         """
         if self.cached_mel_emb is None:
             raise RuntimeError("generate(): call store_mel_emb first (model_v2.py:137)")
-        if num_beams != 1:
-            raise NotImplementedError("beam-sample (num_beams>1) is not implemented in the HIP engine yet")
+        if num_beams != 1 and (num_beams > self.max_batch or not do_sample or length_penalty != 0.0):
+            raise NotImplementedError("beam mode needs max_batch >= num_beams, do_sample=True and length_penalty=0.0 (the served configuration)")
         if logits_processor is not None and len(logits_processor) > 0:
             raise NotImplementedError("custom logits processors (typical sampling) are not implemented in the HIP engine")
         if inputs.shape[0] != 1 or num_return_sequences != 1:
@@ -172,6 +200,19 @@ class GptEngine:
         max_new = (max_length - P) if max_length is not None else (self.max_seq - P - 2)
         max_new = max(0, min(max_new, self.max_seq - P - 2))
         self.prefill(0, emb, n_pad)
+        if num_beams != 1:
+            # served default: 3-beam beam-sample (infer_v2.py:598-605,641-658)
+            self.beam_begin(num_beams)
+            done_steps, fin = 0, False
+            ids = np.zeros(0, np.int32)
+            while done_steps < max_new and not fin:
+                n = min(sync_every, max_new - done_steps)
+                self.beam_decode(n, repetition_penalty=repetition_penalty, temperature=temperature, top_k=top_k, top_p=top_p,
+                                 suppress_stop=suppress_stop, seed=int(unused.get("seed", 0)))
+                done_steps += n
+                ids, fin = self.beam_read(max_new)[:2]
+            out = torch.cat([inputs.reshape(1, -1).to(torch.long).cpu(), torch.from_numpy(ids.astype(np.int64)).reshape(1, -1)], dim=1)
+            return out.to(inputs.device)
         done = 0
         ids, fin = np.zeros(0, np.int32), False
         while done < max_new and not fin:
