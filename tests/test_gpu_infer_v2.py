@@ -1,0 +1,122 @@
+"""Outer boundary: `indextts.infer_v2.IndexTTS2.infer(...)` contract (infer_v2.py:438-461,740-783) with the two
+hot stages on the HIP path and synthetic stand-ins for the PyTorch glue stages this repo does not build."""
+import os
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeGlue:
+    """Deterministic stand-in for the glue stages (shapes as in SURVEY.md 8(d) config 1)."""
+
+    def __init__(self, D, dev, frames_per_code=1.72):
+        self.D, self.dev = D, dev
+        self.calls = dict(speaker=0, emotion=0, s2mel=0)
+        self.g = torch.Generator().manual_seed(5)
+
+    def tokenize(self, text, max_text_tokens_per_segment, quick_streaming_tokens=0):
+        ids = [2 + (ord(c) % 190) for c in text]
+        return [ids[i:i + max_text_tokens_per_segment] for i in range(0, len(ids), max_text_tokens_per_segment)]
+
+    def speaker(self, spk_audio_prompt):
+        self.calls["speaker"] += 1
+        return dict(spk_cond_emb=torch.randn(1, 20, 16, generator=self.g).to(self.dev), style=torch.randn(1, 192, generator=self.g).to(self.dev),
+                    prompt_condition=None, ref_mel=None)
+
+    def emotion(self, emo_audio_prompt):
+        self.calls["emotion"] += 1
+        return torch.randn(1, 20, 16, generator=self.g).to(self.dev)
+
+    def emo_vector_mix(self, emo_vector, style, use_random):
+        w = torch.tensor(emo_vector)
+        return torch.full((1, self.D), 0.01 * float(w.sum()), device=self.dev), float(w.sum())
+
+    def merge_emovec(self, spk_cond_emb, emo_cond_emb, alpha):
+        base = spk_cond_emb.mean(dim=(1, 2)).reshape(1, 1).expand(1, self.D)
+        emo = emo_cond_emb.mean(dim=(1, 2)).reshape(1, 1).expand(1, self.D)
+        return (base + alpha * (emo - base)).contiguous()
+
+    def get_conditioning(self, spk_cond_emb):
+        return torch.linspace(-0.5, 0.5, 32 * self.D, device=self.dev).reshape(32, self.D)
+
+    def s2mel(self, latent, codes, code_lens, speaker):
+        self.calls["s2mel"] += 1
+        F = int(int(code_lens[0]) * 1.72)
+        assert latent.shape == (1, codes.shape[1], self.D)
+        mel = (torch.randn(1, 80, F, generator=torch.Generator().manual_seed(F)) * 2 - 4).clamp(-11.5, 2)
+        return mel.to(self.dev)
+
+
+@pytest.fixture(scope="module")
+def tts():
+    import voice_tts_amd.weights as WR
+    from indextts.infer_v2 import IndexTTS2
+
+    dev = torch.device("cuda:0")
+    gcfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2)
+    bcfg = WR.tiny_bigvgan_cfg(64)
+    Wg = WR.make_gpt_weights(gcfg, seed=7)
+    Wb = WR.make_bigvgan_weights(bcfg, seed=8)
+    glue = FakeGlue(128, dev)
+    m = IndexTTS2(cfg_path=None, model_dir="/nonexistent", use_fp16=False, device="cuda:0", use_cuda_kernel=True, glue=glue,
+                  gpt_state_dict=Wg, bigvgan_state_dict=Wb, gpt_cfg=gcfg, bigvgan_cfg=bcfg, max_seq=192, max_frames=128)
+    return m, glue
+
+
+def test_infer_returns_reference_shaped_audio(tts, tmp_path):
+    m, glue = tts
+    text = "abcdefghijklmnopqrstuvwxyz0123456789" * 2  # 72 tokens -> 3 segments of <= 30
+    # greedy path through the served kwargs (top_k=1), short generations
+    res = m.infer("spk.wav", text, None, max_text_tokens_per_segment=30, num_beams=1, top_k=1, max_mel_tokens=20)
+    sr, pcm = res
+    assert sr == 22050 and pcm.dtype == np.int16 and pcm.ndim == 2 and pcm.shape[1] == 1
+    frames = int(20 * 1.72)
+    expect = 3 * frames * 256 + 2 * int(22050 * 0.2)  # 3 segments + 2 x 200 ms silence (infer_v2.py:283-304,752)
+    assert pcm.shape[0] == expect
+    assert np.abs(pcm).max() <= 32767
+    assert glue.calls["speaker"] == 1 and glue.calls["s2mel"] == 3
+    t = m.last_timing
+    assert t["audio_length"] == pytest.approx(expect / 22050)
+    # same speaker prompt object again -> cached (infer_v2.py:508-550); output file variant
+    out = str(tmp_path / "o" / "x.wav")
+    assert m.infer("spk.wav", "hello world", out, num_beams=1, top_k=1, max_mel_tokens=12) == out
+    with wave.open(out) as f:
+        assert (f.getnchannels(), f.getsampwidth(), f.getframerate()) == (1, 2, 22050)
+        assert f.getnframes() == int(12 * 1.72) * 256
+    # empty text -> no segments -> None (infer_v2.py:460-461)
+    assert m.infer("spk.wav", "", None) is None
+
+
+def test_stream_return_and_served_defaults(tts):
+    m, glue = tts
+    # served defaults: num_beams=3 beam-sample, top_k 30, top_p .8, temperature .8, repetition_penalty 10 (infer_v2.py:598-606)
+    gen = m.infer("spk2.wav", "abcdefghij" * 5, None, max_text_tokens_per_segment=25, stream_return=True, max_mel_tokens=16,
+                  emo_vector=[0.1, 0, 0, 0, 0, 0, 0, 0.2], seed=11)
+    chunks = list(gen)
+    # per segment: wav tensor then the silence tensor (infer_v2.py:745-749); nothing else when stream_return
+    assert len(chunks) == 4
+    for i, c in enumerate(chunks):
+        assert isinstance(c, torch.Tensor) and c.dim() == 2 and c.shape[0] == 1 and c.device.type == "cpu"
+        if i % 2 == 1:
+            assert c.shape[1] == int(22050 * 0.2) and float(c.abs().max()) == 0.0
+        else:
+            assert c.shape[1] % 256 == 0 and c.shape[1] > 0 and float(c.abs().max()) <= 32767.0
+
+
+def test_missing_glue_is_loud():
+    import voice_tts_amd.weights as WR
+    from indextts.infer_v2 import IndexTTS2
+
+    gcfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2)
+    bcfg = WR.tiny_bigvgan_cfg(64)
+    m = IndexTTS2(cfg_path=None, model_dir="/nonexistent", device="cuda:0", gpt_state_dict=WR.make_gpt_weights(gcfg, seed=7),
+                  bigvgan_state_dict=WR.make_bigvgan_weights(bcfg, seed=8), gpt_cfg=gcfg, bigvgan_cfg=bcfg, max_seq=96, max_frames=32)
+    assert m.device.type == "cuda" and m.use_fp16 is False  # attributes server.py:306-307 reads
+    with pytest.raises(NotImplementedError):
+        m.infer("spk.wav", "hi", None)
+    with pytest.raises(FileNotFoundError):
+        IndexTTS2(cfg_path=None, model_dir="/nonexistent", device="cuda:0")

@@ -100,3 +100,14 @@ if "micro" in what:
         g.replay()
         ms = ev_time(lambda: g.replay(), 20) / 200
     print(f"micro trivial kernel in graph: {ms*1e3:.2f} us", flush=True)
+
+if "beam" in what:
+    W = WR.make_gpt_weights(WR.GPT_CFG, seed=1234)
+    eng = GptEngine(WR.GPT_CFG, dtype="bf16", max_seq=2048, max_batch=3, device=dev).load_state_dict(W)
+    emb = torch.randn(136, 1280, generator=torch.Generator().manual_seed(1)) * 0.5
+    eng.prefill(0, emb, 0)
+    eng.beam_begin(3)
+    eng.beam_decode(16, suppress_stop=True)
+    ms = ev_time(lambda: eng.beam_decode(96, suppress_stop=True), 3) / 96
+    ids, done, score, bs, lt, src = eng.beam_read(2000)
+    print(f"beam-sample bf16 3 beams: {ms*1e3:.1f} us/step, {len(ids)} ids, score {score:.1f}, done {done}", flush=True)
