@@ -4,7 +4,7 @@
 // call site indextts/infer_v2.py:154-158,735.
 //
 // HBM layout
-//   weight arena (one hipMalloc, broadcastable): per conv  Wp[phase][tap][Cin_pad][Cout_pad] fp32
+//   weight arena (one hipMalloc, broadcastable): per conv  Wq[phase][tap][Cin_pad/8][2][Cout_pad][4] fp32
 //   + bias[Cout]; per activation log_alpha[C], log_beta[C]; the 12 filter taps.
 //   activations: 5 ping-pong buffers of 6144*F*B floats ([B][C][T] row-major, T contiguous):
 //     XS  previous stage output / 3-way resblock accumulator      X   stage input (after ups)
@@ -207,23 +207,25 @@ extern "C" int ixtts_bigvgan_set_tensor(ixtts_bigvgan* h, const char* name, cons
     return IXTTS_OK;
   }
   std::vector<float> packed((size_t)d.K * d.Cin_pad * d.Cout_pad, 0.f);
+  // destination index of weight (tapslot, ci, co): Wq[tapslot][ci/8][ci%2][co][(ci%8)/2]   (conv1d.hip)
+  const int ngroups = d.Cin_pad / 8;
+  auto qidx = [&](int tapslot, int ci, int co) -> size_t {
+    const int g = ci / 8, r = ci % 8;
+    return ((((size_t)tapslot * ngroups + g) * 2 + (r & 1)) * d.Cout_pad + co) * 4 + (r >> 1);
+  };
   if (d.stride == 1) {
-    // Conv1d weight [Cout][Cin][K] -> Wp[k][ci][co]
+    // Conv1d weight [Cout][Cin][K]
     IX_ARG(shape[0] == d.Cout && shape[1] == d.Cin && shape[2] == d.K, "bigvgan_set_tensor: %s expects [%d,%d,%d]", name, d.Cout, d.Cin, d.K);
     for (int co = 0; co < d.Cout; ++co)
       for (int ci = 0; ci < d.Cin; ++ci)
-        for (int k = 0; k < d.K; ++k)
-          packed[((size_t)k * d.Cin_pad + ci) * d.Cout_pad + co] = data[((size_t)co * d.Cin + ci) * d.K + k];
+        for (int k = 0; k < d.K; ++k) packed[qidx(k, ci, co)] = data[((size_t)co * d.Cin + ci) * d.K + k];
   } else {
-    // ConvTranspose1d weight [Cin][Cout][K] -> Wp[phase r][j][ci][co], k = r + stride*j
+    // ConvTranspose1d weight [Cin][Cout][K] -> tap slot = phase r * (K/stride) + j, k = r + stride*j
     IX_ARG(shape[0] == d.Cin && shape[1] == d.Cout && shape[2] == d.K, "bigvgan_set_tensor: %s expects [%d,%d,%d]", name, d.Cin, d.Cout, d.K);
-    int J = d.K / d.stride;
+    const int J = d.K / d.stride;
     for (int ci = 0; ci < d.Cin; ++ci)
       for (int co = 0; co < d.Cout; ++co)
-        for (int k = 0; k < d.K; ++k) {
-          int r = k % d.stride, j = k / d.stride;
-          packed[(((size_t)r * J + j) * d.Cin_pad + ci) * d.Cout_pad + co] = data[((size_t)ci * d.Cout + co) * d.K + k];
-        }
+        for (int k = 0; k < d.K; ++k) packed[qidx((k % d.stride) * J + k / d.stride, ci, co)] = data[((size_t)ci * d.Cout + co) * d.K + k];
   }
   IX_HIP(hipMemcpy(h->arena + d.w_off, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
   d.w_set = true;

@@ -13,9 +13,10 @@
 //   * MFMA `v_mfma_f32_32x32x2_f32`: exact fp32 (a k-ordered fmaf chain), 157 TFLOP/s peak --
 //     the vocoder must stay fp32 for the 1e-3 waveform budget and the fused network is
 //     compute-bound, so this is the binding roofline.
-//   * weights are pre-packed [tap][ci][co] so a 32-lane half-wave reads 128 contiguous
-//     bytes per A fragment; the x tile (+dilation halo) is staged once per K-chunk in LDS
-//     and every tap re-reads it at a shifted offset (no im2col in memory).
+//   * weights are pre-packed [tap][ci/8][ci%2][co][(ci%8)/2]: one float4 per lane = the A operand of 4
+//     k-steps, streamed from L2 into registers one tap ahead (no LDS round trip for weights);
+//     the x tile of 32 input channels (+dilation halo) is staged once per K-chunk in LDS and
+//     every tap re-reads it at a shifted offset (no im2col in memory).
 //   * bias / residual add / 3-way resblock accumulate (/3) are fused into the epilogue.
 //   * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each take a contiguous run of
 //     tiles (same co rows), so one XCD's L2 holds one slice of the weights.
@@ -25,14 +26,19 @@ namespace ixtts {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CK = 8;  // input channels per K-chunk
+constexpr int CG = 8;   // input channels per weight group (one float4 per lane = 4 MFMA k-steps)
+constexpr int CKG = 4;  // groups per K-chunk: the x tile in LDS covers 32 input channels
 
+// Weights are packed Wq[phase][tap][ci/8][ci%2][co][(ci%8)/2]: lane (co = l31, k-parity = lh) reads ONE float4
+// holding its A operand for the 4 consecutive k-steps of a channel group; a half-wave reads 512 contiguous bytes.
+// They stream from L2 (the XCD-aware tile map keeps one co-slice per XCD) straight into registers, one tap ahead;
+// only the x tile (+dilation halo) lives in LDS.
 template <int MT, int NT, int WM, int WN>
 __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvParams p) {
   constexpr int BM = 32 * MT * WM;
   constexpr int BN = 32 * NT * WN;
   static_assert(WM * WN == 4, "4 waves per workgroup");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  extern __shared__ __attribute__((aligned(16))) float Xs[];  // [CKG*CG][XWP]
 
   // ---- XCD-aware tile id (blocks b and b+8 share an XCD; give each XCD a contiguous run)
   const int nwg = p.n_tiles * p.m_tiles;
@@ -51,9 +57,6 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvParams p) {
   const int span = (p.ntap - 1) * adil;
   const int XW = BN + span;
   const int XWP = XW | 1;  // odd row pitch
-  float* Xs = smem;                 // [CK][XWP]
-  float* Ws = smem + CK * XWP;      // [ntap][CK][BM]
-  Ws = (float*)(((uintptr_t)Ws + 15) & ~(uintptr_t)15);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -70,53 +73,80 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const float* xb = p.x + (size_t)b * p.Cin * p.Tin;
-  const float* wph = p.wp + (size_t)phase * p.ntap * p.Cin_pad * p.Cout_pad;
-  // smallest input index any tap of this tile touches
-  const int lo = q0 + p.off0 - (p.dil < 0 ? span : 0);
+  const int ngroups = p.Cin_pad / CG;
+  // A operand base of this lane: [.. tap][group][lh][co][4]
+  const float4* wq = reinterpret_cast<const float4*>(p.wp) + (size_t)phase * p.ntap * ngroups * 2 * p.Cout_pad +
+                     (size_t)lh * p.Cout_pad + m0 + wm * (32 * MT) + l31;
+  const size_t gstride = (size_t)2 * p.Cout_pad;       // float4 per group
+  const size_t tstride = (size_t)ngroups * gstride;    // float4 per tap
+  const int lo = q0 + p.off0 - (p.dil < 0 ? span : 0);  // smallest input index any tap of this tile touches
 
-  for (int c0 = 0; c0 < p.Cin_pad; c0 += CK) {
+  for (int g0 = 0; g0 < ngroups; g0 += CKG) {
+    const int ng = min(CKG, ngroups - g0);
     __syncthreads();
-    // ---- stage x tile: CK rows x XW columns (zero outside [0,Tin) / beyond Cin)
+    // ---- stage x tile: ng*8 rows x XW columns (zero outside [0,Tin) / beyond Cin).  One channel group at a
+    // time: its 8 rows x up-to-2 columns per thread are all in flight before the first LDS store (16 temporaries;
+    // unrolling the whole 32-row chunk -- or a register-prefetched double buffer -- pushed the kernel past 200 VGPRs
+    // and to occupancy 1, which measured slower).
+    for (int gg = 0; gg < ng; ++gg) {
+      float v[CG][2];
 #pragma unroll
-    for (int ci = 0; ci < CK; ++ci) {
-      const bool crow = (c0 + ci) < p.Cin;
-      const float* xr = xb + (size_t)(c0 + ci) * p.Tin;
-      for (int j = tid; j < XW; j += 256) {
-        int t = lo + j;
-        float v = 0.f;
-        if (crow && t >= 0 && t < p.Tin) v = xr[t];
-        Xs[ci * XWP + j] = v;
+      for (int r = 0; r < CG; ++r) {
+        const int c = (g0 + gg) * CG + r;
+        const float* xr = xb + (size_t)c * p.Tin;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = tid + jj * 256, t = lo + j;
+          v[r][jj] = (j < XW && c < p.Cin && t >= 0 && t < p.Tin) ? xr[t] : 0.f;
+        }
       }
-    }
-    // ---- stage weight tile: ntap*CK rows of BM floats
-    {
-      constexpr int V4 = BM / 4;
-      const int rows = p.ntap * CK;
-      for (int i = tid; i < rows * V4; i += 256) {
-        int row = i / V4, c4 = i - row * V4;
-        int tap = row / CK, ci = row - tap * CK;
-        const float4 v = *reinterpret_cast<const float4*>(wph + ((size_t)tap * p.Cin_pad + c0 + ci) * p.Cout_pad + m0 + c4 * 4);
-        *reinterpret_cast<float4*>(Ws + row * BM + c4 * 4) = v;
-      }
+#pragma unroll
+      for (int r = 0; r < CG; ++r)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = tid + jj * 256;
+          if (j < XW) Xs[(gg * CG + r) * XWP + j] = v[r][jj];
+        }
     }
     __syncthreads();
-    // ---- MFMA over taps x channel pairs
+    const float* Xc = Xs;
+    // ---- taps: A fragments one tap ahead in registers, B fragments from the LDS tile at a shifted offset
+    float4 a_cur[CKG][MT], a_nxt[CKG][MT];
+#pragma unroll
+    for (int gg = 0; gg < CKG; ++gg)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a_cur[gg][i] = (gg < ng) ? wq[(size_t)(g0 + gg) * gstride + i * 32] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int tap = 0; tap < p.ntap; ++tap) {
-      const int xoff = (p.dil >= 0) ? tap * adil : (p.ntap - 1 - tap) * adil;
-      const float* wrow = Ws + (tap * CK + lh) * BM + wm * (32 * MT) + l31;
-      const float* xrow = Xs + lh * XWP + wn * (32 * NT) + l31 + xoff;
+      if (tap + 1 < p.ntap) {
 #pragma unroll
-      for (int kk = 0; kk < CK / 2; ++kk) {
-        float a[MT], bb[NT];
+        for (int gg = 0; gg < CKG; ++gg)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = wrow[kk * 2 * BM + i * 32];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bb[j] = xrow[kk * 2 * XWP + j * 32];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < MT; ++i)
+            a_nxt[gg][i] = (gg < ng) ? wq[(size_t)(tap + 1) * tstride + (size_t)(g0 + gg) * gstride + i * 32] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+      const int xoff = (p.dil >= 0) ? tap * adil : (p.ntap - 1 - tap) * adil;
+      const float* xrow = Xc + lh * XWP + wn * (32 * NT) + l31 + xoff;
+#pragma unroll
+      for (int gg = 0; gg < CKG; ++gg) {
+        if (gg < ng) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            float bb[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bb[j] = xrow[(gg * CG + 2 * kk) * XWP + j * 32];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              const float av = kk == 0 ? a_cur[gg][i].x : kk == 1 ? a_cur[gg][i].y : kk == 2 ? a_cur[gg][i].z : a_cur[gg][i].w;
+#pragma unroll
+              for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bb[j], acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int gg = 0; gg < CKG; ++gg)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a_cur[gg][i] = a_nxt[gg][i];
     }
   }
 
@@ -156,8 +186,9 @@ static int launch_cfg(const ConvParams& p0, hipStream_t st) {
   IX_ARG(p.Cout_pad % BM == 0 && p.Cout_pad >= p.m_tiles * BM, "conv: Cout_pad %d not a multiple of BM %d", p.Cout_pad, BM);
   int adil = p.dil < 0 ? -p.dil : p.dil;
   int XWP = (BN + (p.ntap - 1) * adil) | 1;
-  size_t smem = (size_t)(CK * XWP + 4 + p.ntap * CK * BM) * sizeof(float);
+  size_t smem = (size_t)(CKG * CG * XWP) * sizeof(float);
   IX_ARG(smem <= 160 * 1024, "conv: LDS tile %zu B too large", smem);
+  IX_ARG(BN + (p.ntap - 1) * adil <= 512, "conv: x tile of %d columns exceeds the staging bound (512)", BN + (p.ntap - 1) * adil);
   auto kern = conv1d_mfma_kernel<MT, NT, WM, WN>;
   if (smem > 64 * 1024) {
     static bool done = false;
@@ -172,7 +203,7 @@ static int launch_cfg(const ConvParams& p0, hipStream_t st) {
   return IXTTS_OK;
 }
 
-// tile shape id chosen at pack time from Cout (see conv_tile_bm)
+// Cout padding granule chosen at pack time (a multiple of every BM that may be used for this Cout)
 int conv_tile_bm(int Cout) {
   if (Cout <= 32) return 32;
   if (Cout <= 64) return 64;
@@ -180,13 +211,27 @@ int conv_tile_bm(int Cout) {
   return 128;
 }
 
+// Workgroups of one launch run as ceil(wgs / 256) "rounds" over the 256 CUs (co-resident workgroups of a CU share
+// its matrix pipe), so a grid of 375 tiles costs as much as 512.  Score = tile-quantisation efficiency x a mild
+// preference for bigger tiles (fewer LDS/L2 bytes per flop).
+static double tile_score(const ConvParams& p, int BM, int BN, double pref) {
+  const double wgs = (double)ceil_div(p.Cout, BM) * ceil_div(p.Nq, BN) * p.B * p.nphase;
+  const double rounds = (double)(((long long)wgs + 255) / 256);
+  return wgs / (rounds * 256.0) * pref;
+}
+
 int launch_conv1d(const ConvParams& p, hipStream_t st) {
-  IX_ARG(p.Cin_pad % CK == 0, "conv: Cin_pad %d not a multiple of %d", p.Cin_pad, CK);
+  IX_ARG(p.Cin_pad % CG == 0, "conv: Cin_pad %d not a multiple of %d", p.Cin_pad, CG);
   switch (conv_tile_bm(p.Cout)) {
     case 32: return launch_cfg<1, 2, 1, 4>(p, st);   // 32 x 256
     case 64: return launch_cfg<2, 1, 1, 4>(p, st);   // 64 x 128
     case 96: return launch_cfg<3, 1, 1, 4>(p, st);   // 96 x 128
-    default: return launch_cfg<2, 2, 2, 2>(p, st);   // 128 x 128
+    default: {
+      const double s128 = tile_score(p, 128, 128, 1.00), s64x128 = tile_score(p, 64, 128, 0.96), s64 = tile_score(p, 64, 64, 0.90);
+      if (s128 >= s64x128 && s128 >= s64) return launch_cfg<2, 2, 2, 2>(p, st);  // 128 x 128
+      if (s64x128 >= s64) return launch_cfg<1, 2, 2, 2>(p, st);                  // 64 x 128
+      return launch_cfg<1, 1, 2, 2>(p, st);                                      // 64 x 64
+    }
   }
 }
 
