@@ -27,7 +27,7 @@ def ev_time(fn, n):
 if "bigvgan" in what:
     t0 = time.time()
     W = WR.make_bigvgan_weights(WR.BIGVGAN_CFG, seed=1234)
-    m = BigVGAN(WR.BIGVGAN_CFG, max_frames=2048, device=dev).load_state_dict(W)
+    m = BigVGAN(WR.BIGVGAN_CFG, max_frames=2048, fast_sin="fast" in what, device=dev).load_state_dict(W)
     print(f"bigvgan load {time.time()-t0:.1f}s", flush=True)
     for F in (1000, 1892):
         mel = (torch.randn(1, 80, F, generator=torch.Generator().manual_seed(6)) * 2 - 4).clamp(-11.5, 2).to(dev)

@@ -18,7 +18,7 @@ namespace ixtts {
 
 constexpr int AA_TILE = 1024;    // outputs per workgroup
 constexpr int AA_THREADS = 256;  // 4 waves
-constexpr int AA_XH = 6;         // x halo each side
+constexpr int AA_XH = 7;         // x halo each side
 constexpr int AA_NX = AA_TILE + 2 * AA_XH;
 constexpr int AA_NS = 2 * AA_TILE + 12;  // s[2*t0-5 .. 2*(t0+TILE)+6]
 
@@ -66,22 +66,29 @@ __global__ __launch_bounds__(AA_THREADS) void aa_snake_kernel(const float* __res
   }
   __syncthreads();
 
-  // phase 1: s over j in [2*t0-5, 2*t0-5+NS), clamped to [0, 2T-1]
-  const int j0 = 2 * t0 - 5;
-  for (int i = threadIdx.x; i < AA_NS; i += AA_THREADS) {
-    int j = min(max(j0 + i, 0), 2 * T - 1);
-    int m = j >> 1;
-    // x index base (unclamped) for tap a=0: even -> m-3, odd -> m-2
-    int odd = j & 1;
-    int xb = m - 3 + odd;
-    float acc = 0.f;
+  // phase 1: one (even, odd) pair of up-sampled Snake values per thread-iteration.  Pair p <-> m = t0-3+p
+  // owns s[2m] -> ss[2p-1] and s[2m+1] -> ss[2p]; both share the 7 staged inputs x[m-3..m+3] (xs is already
+  // replicate-clamped, so no per-tap index clamps).  Replicate padding of s: m < 0 -> s[0], m > T-1 -> s[2T-1].
+  for (int pr = threadIdx.x; pr < AA_TILE + 7; pr += AA_THREADS) {
+    const int m = t0 - 3 + pr;
+    const int mc = min(max(m, 0), T - 1);
+    const float* xp = xs + (mc - 3) - (t0 - AA_XH);  // x[mc-3] .. x[mc+3]
+    float xw[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) xw[i] = xp[i];
+    float ue = 0.f, uo = 0.f;
 #pragma unroll
     for (int aa = 0; aa < 6; ++aa) {
-      int xi = min(max(xb + aa, 0), T - 1);
-      float f = odd ? fu[10 - 2 * aa] : fu[11 - 2 * aa];
-      acc = fmaf(f, xs[xi - (t0 - AA_XH)], acc);
+      ue = fmaf(fu[11 - 2 * aa], xw[aa], ue);      // u[2m]   = 2 * sum_a f[11-2a] x[m-3+a]
+      uo = fmaf(fu[10 - 2 * aa], xw[aa + 1], uo);  // u[2m+1] = 2 * sum_a f[10-2a] x[m-2+a]
     }
-    ss[i] = snake<FAST_SIN>(2.0f * acc, a, inv_b);
+    float se = snake<FAST_SIN>(2.0f * ue, a, inv_b);
+    float so = snake<FAST_SIN>(2.0f * uo, a, inv_b);
+    if (m < 0) so = se;
+    if (m > T - 1) se = so;
+    const int ie = 2 * pr - 1;
+    if (ie >= 0 && ie < AA_NS) ss[ie] = se;
+    if (ie + 1 < AA_NS) ss[ie + 1] = so;
   }
   __syncthreads();
 
