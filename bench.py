@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--tokens", type=int, default=100, help="text tokens per segment")
     ap.add_argument("--codes", type=int, default=1100, help="mel codes per segment (11 per char)")
     ap.add_argument("--segments", type=int, default=2)
+    ap.add_argument("--no-s2mel", action="store_true", help="leave the PyTorch-glue s2mel stage out of the timed region (feed synthetic mels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -87,10 +88,16 @@ def main():
     # ---- load: rank 0 builds the (synthetic, seeded) weights, RCCL broadcasts the packed arenas
     t_load = time.time()
     Wg = Wb = None
+    use_s2mel = not args.no_s2mel
     if rank == 0:
         Wg = WR.make_gpt_weights(WR.GPT_CFG, seed=1234)
         Wb = WR.make_bigvgan_weights(WR.BIGVGAN_CFG, seed=1234)
         hp.load(Wg, Wb)
+    if use_s2mel:
+        # PyTorch glue stage (row N1): every rank regenerates the same seeded weights (98 M params, plain torch tensors)
+        import voice_tts_amd.s2mel as S2
+
+        hp.attach_s2mel(S2.make_s2mel_weights(S2.S2MEL_CFG, seed=1234))
     if world > 1:
         for t in hp.broadcast_tensors():
             dist.broadcast(t, src=0)
@@ -105,9 +112,14 @@ def main():
     conds = [(torch.randn(34, D, generator=g) * 0.5).to(dev) for _ in range(n_seg)]
     texts = [torch.randint(2, 12000, (n_tok,), generator=g) for _ in range(n_seg)]
     mels = [(torch.randn(1, 80, frames, generator=g) * 2 - 4).clamp(-11.5, 2).to(dev) for _ in range(n_seg)]
+    # 5 s speaker prompt -> 430 reference mel frames: stand-ins for the cached prompt features
+    Tref = 430
+    prompt_condition = torch.randn(1, Tref, 512, generator=g).to(dev)
+    ref_mel = (torch.randn(1, 80, Tref, generator=g) * 2 - 4).clamp(-11.5, 2).to(dev)
+    style = torch.randn(1, 192, generator=g).to(dev)
     audio_s = audio_seconds([n_codes] * n_seg)
 
-    stage_ms = {"gpt_gen": 0.0, "gpt_forward": 0.0, "bigvgan": 0.0}
+    stage_ms = {"gpt_gen": 0.0, "gpt_forward": 0.0, "s2mel": 0.0, "bigvgan": 0.0}
 
     def request(timed):
         def tick():
@@ -120,15 +132,23 @@ def main():
         t1 = tick()
         lats = [hp.latent(conds[s], texts[s], codes[s]) for s in range(n_seg)]
         t2 = tick()
+        if use_s2mel:  # 25 Euler steps x CFG batch 2 over T = 430 + 1892 frames, fp32 (infer_v2.py:713-731)
+            seg_mels = [hp.s2mel(lats[s], codes[s], prompt_condition, ref_mel, style) for s in range(n_seg)]
+            # synthetic weights give arbitrary mel statistics; keep the vocoder input in the log-mel range it is built for
+            seg_mels = [m.clamp(-11.5, 2.0) for m in seg_mels]
+        else:
+            seg_mels = mels
+        t2b = tick()
         wavs = []
         for s in range(n_seg):
-            w = hp.vocode(mels[s])
+            w = hp.vocode(seg_mels[s])
             wavs.append(w.to(torch.int16).cpu())  # wav.cpu() per segment, int16 truncation (infer_v2.py:744,781)
         t3 = tick()
         if timed:
             stage_ms["gpt_gen"] += (t1 - t0) * 1e3
             stage_ms["gpt_forward"] += (t2 - t1) * 1e3
-            stage_ms["bigvgan"] += (t3 - t2) * 1e3
+            stage_ms["s2mel"] += (t2b - t2) * 1e3
+            stage_ms["bigvgan"] += (t3 - t2b) * 1e3
         assert all(len(c) == n_codes for c in codes) and all(l.shape == (n_codes, D) for l in lats)
         assert all(w.shape[-1] == frames * 256 for w in wavs)
         return codes
@@ -258,11 +278,14 @@ def main():
             "rtf": round(elapsed / (audio_s * args.steps), 5),
             "config": {
                 "workload": f"1 /tts request per GPU: {n_seg}x{n_tok}-token zh text segments (200-char utterance), greedy fixed-length "
-                            f"decode {n_codes} codes/segment batched B={n_seg}, latent GPT forward, BigVGAN {frames} frames/segment -> "
-                            f"{audio_s:.2f} s audio; conditioning encoders + s2mel not built: conds_latent/mel are synthetic HBM-resident inputs",
+                            f"decode {n_codes} codes/segment batched B={n_seg}, latent GPT forward, "
+                            + ("s2mel (length regulator + 25-step CFM/DiT, PyTorch-ROCm glue, fp32, 430-frame prompt), " if use_s2mel else "s2mel skipped (synthetic mel), ")
+                            + f"BigVGAN {frames} frames/segment -> {audio_s:.2f} s audio; prompt feature extraction and conditioning "
+                            f"encoders not built: conds_latent / prompt_condition / ref_mel / style are synthetic HBM-resident inputs",
                 "segments": n_seg, "text_tokens_per_segment": n_tok, "codes_per_segment": n_codes, "mel_frames_per_segment": frames,
                 "audio_seconds_per_request": round(audio_s, 3), "parallelism": f"request-per-GPU x{world}, RCCL weight broadcast at load",
                 "gpt_precision": f"{args.dtype} weights+KV, fp32 accumulate", "bigvgan_precision": "fp32 (fp32 MFMA)",
+                "s2mel": "torch fp32 glue in the timed region" if use_s2mel else "excluded",
             },
             "stage_ms_per_step": {k: round(v / args.steps, 2) for k, v in stage_ms.items()},
             "load_s": round(t_load, 1),

@@ -279,6 +279,90 @@ def _gen_beam_case(stop_bias, rng_seed):
                 sequence=seq, sequence_score=fin["sequence_scores"], done=int(bool(scorer.is_done)))
 
 
+# ----------------------------------------------------------------------------- N1 (s2mel glue)
+class _AD(dict):
+    __getattr__ = dict.__getitem__
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _load_folded_into_reference(module, W, prefix):
+    """Put our (weight-norm-folded) tensors into a reference module that still carries weight_g / weight_v."""
+    sd = module.state_dict()
+    new, used = {}, set()
+    for k, v in sd.items():
+        if k.endswith("weight_v") and prefix + k[: -len("weight_v")] + "weight" in W:
+            w = W[prefix + k[: -len("weight_v")] + "weight"]
+            new[k] = w
+            used.add(prefix + k[: -len("weight_v")] + "weight")
+        elif k.endswith("weight_g") and prefix + k[: -len("weight_g")] + "weight" in W:
+            w = W[prefix + k[: -len("weight_g")] + "weight"]
+            new[k] = w.reshape(w.shape[0], -1).norm(dim=1).reshape(v.shape)
+        elif prefix + k in W:
+            assert tuple(W[prefix + k].shape) == tuple(v.shape), (k, W[prefix + k].shape, v.shape)
+            new[k] = W[prefix + k]
+            used.add(prefix + k)
+        else:
+            new[k] = v
+    module.load_state_dict(new, strict=True)
+    return used
+
+
+def gen_s2mel():
+    import voice_tts_amd.s2mel as S2
+    from indextts.s2mel.modules.commons import MyModel
+    from indextts.utils.maskgct.models.codec.amphion_codec.quantize.factorized_vector_quantize import FactorizedVectorQuantize
+
+    cfg = S2.tiny_s2mel_cfg(gpt_dim=1280, semantic_dim=1024, lr_in_channels=1024, codebook_size=8194)
+    W = S2.make_s2mel_weights(cfg, seed=71)
+    args = _AD(
+        reg_loss_type="l1", dit_type="DiT", style_encoder=_AD(dim=cfg["style_dim"]),
+        length_regulator=_AD(channels=cfg["lr_channels"], is_discrete=False, in_channels=cfg["lr_in_channels"], content_codebook_size=2048,
+                             sampling_ratios=[1] * cfg["lr_n_blocks"], vector_quantize=False, n_codebooks=1, quantizer_dropout=0.0,
+                             f0_condition=False, n_f0_bins=512),
+        DiT=_AD(hidden_dim=cfg["hidden_dim"], num_heads=cfg["num_heads"], depth=cfg["depth"], class_dropout_prob=0.1, block_size=8192,
+                in_channels=80, style_condition=True, final_layer_type="wavenet", content_dim=cfg["content_dim"],
+                content_codebook_size=1024, content_type="discrete", is_causal=False, long_skip_connection=True,
+                zero_prompt_speech_token=False, time_as_token=False, style_as_token=False, uvit_skip_connection=True),
+        wavenet=_AD(hidden_dim=cfg["wavenet_hidden"], num_layers=cfg["wavenet_layers"], kernel_size=cfg["wavenet_kernel"],
+                    dilation_rate=cfg["wavenet_dilation_rate"], p_dropout=0.2, style_condition=True),
+    )
+    m = MyModel(args, use_gpt_latent=True).eval()
+    m.models["cfm"].estimator.setup_caches(max_batch_size=2, max_seq_length=64)
+    used = set()
+    for key in ("cfm", "length_regulator", "gpt_layer"):
+        used |= _load_folded_into_reference(m.models[key], W, key + ".")
+    q = FactorizedVectorQuantize(input_dim=cfg["semantic_dim"], codebook_size=cfg["codebook_size"], codebook_dim=cfg["codebook_dim"]).eval()
+    used |= _load_folded_into_reference(q, W, "quantizer.")
+    missing = set(W) - used
+    assert not missing, sorted(missing)[:5]
+
+    g = torch.Generator().manual_seed(72)
+    n, Tp = 5, 7
+    latent = torch.randn(1, n, 1280, generator=g) * 0.5
+    codes = torch.randint(0, 8192, (1, n), generator=g)
+    code_lens = torch.tensor([n])
+    prompt_condition = torch.randn(1, Tp, cfg["content_dim"], generator=g)
+    ref_mel = torch.randn(1, 80, Tp, generator=g) * 2 - 4
+    style = torch.randn(1, cfg["style_dim"], generator=g)
+    # infer_v2.py:713-731 with the reference's own modules
+    lat = m.models["gpt_layer"](latent)
+    S_infer = q.vq2emb(codes).transpose(1, 2) + lat
+    target_lengths = (code_lens * 1.72).long()
+    cond = m.models["length_regulator"](S_infer, ylens=target_lengths, n_quantizers=3, f0=None)[0]
+    cat_condition = torch.cat([prompt_condition, cond], dim=1)
+    T = cat_condition.shape[1]
+    noise = torch.randn(1, 80, T, generator=g)
+    cfm = m.models["cfm"]
+    t_span = torch.linspace(0, 1, 4)
+    with torch.inference_mode():
+        mel = cfm.solve_euler(noise.clone(), torch.LongTensor([T]), ref_mel, cat_condition.clone(), style, None, t_span, inference_cfg_rate=0.7)
+        one = cfm.estimator(noise, torch.zeros_like(noise), torch.LongTensor([T]), torch.tensor([0.3]), style, cat_condition)
+    save("s2mel_tiny.npz", seed=71, latent=latent, codes=codes, prompt_condition=prompt_condition, ref_mel=ref_mel, style=style,
+         noise=noise, gpt_layer_out=lat, vq_emb=q.vq2emb(codes).transpose(1, 2), cond=cond, dit_one=one, mel=mel[:, :, Tp:], n_steps=3)
+
+
 # ----------------------------------------------------------------------------- G8
 def gen_sampler():
     from transformers.generation.logits_process import (
@@ -304,7 +388,7 @@ def gen_sampler():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["aa", "bigvgan", "gpt", "prod", "sampler", "beam"]
+    which = sys.argv[1:] or ["aa", "bigvgan", "gpt", "prod", "sampler", "beam", "s2mel"]
     if "aa" in which:
         gen_aa_snake()
     if "bigvgan" in which:
@@ -317,3 +401,5 @@ if __name__ == "__main__":
         gen_sampler()
     if "beam" in which:
         gen_beam()
+    if "s2mel" in which:
+        gen_s2mel()

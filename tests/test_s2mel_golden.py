@@ -1,0 +1,64 @@
+"""Row N1 (PyTorch glue): the s2mel stage restated in voice-tts_amd/s2mel.py against outputs of the reference's own
+MyModel / InterpolateRegulator / CFM(DiT + WaveNet) / FactorizedVectorQuantize (tests/golden/s2mel_tiny.npz).
+Pure torch, so it runs on the CPU here and on the GPU in test_gpu_s2mel."""
+import numpy as np
+import pytest
+import torch
+
+import voice_tts_amd.s2mel as S2
+
+
+def _model(g, device="cpu"):
+    cfg = S2.tiny_s2mel_cfg(gpt_dim=1280, semantic_dim=1024, lr_in_channels=1024, codebook_size=8194)
+    W = S2.make_s2mel_weights(cfg, seed=int(g["seed"]))
+    return S2.S2Mel(W, cfg, device=device), cfg
+
+
+def _t(g, k, device="cpu"):
+    return torch.from_numpy(g[k]).to(device)
+
+
+def test_s2mel_stages_vs_reference(golden):
+    g = golden("s2mel_tiny.npz")
+    m, cfg = _model(g)
+    lat = m.gpt_layer(_t(g, "latent"))
+    assert torch.allclose(lat, _t(g, "gpt_layer_out"), atol=2e-5)
+    emb = m.vq2emb(_t(g, "codes"))
+    assert torch.allclose(emb, _t(g, "vq_emb"), atol=1e-5)
+    n = g["codes"].shape[1]
+    cond = m.length_regulator(emb + lat, torch.tensor([int(n * 1.72)]))
+    assert cond.shape == _t(g, "cond").shape and torch.allclose(cond, _t(g, "cond"), atol=2e-5)
+    # one DiT evaluation (transformer with RoPE + U-ViT skips + AdaLN-RMSNorm, WaveNet head, final layer)
+    cat = torch.cat([_t(g, "prompt_condition"), cond], dim=1)
+    T = cat.shape[1]
+    one = m.dit(_t(g, "noise"), torch.zeros(1, 80, T), torch.tensor([T]), torch.tensor([0.3]), _t(g, "style"), cat)
+    ref = _t(g, "dit_one")
+    assert (one - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_s2mel_end_to_end_vs_reference(golden):
+    g = golden("s2mel_tiny.npz")
+    m, cfg = _model(g)
+    n = g["codes"].shape[1]
+    mel = m(_t(g, "latent"), _t(g, "codes"), torch.tensor([n]), _t(g, "prompt_condition"), _t(g, "ref_mel"), _t(g, "style"),
+            n_timesteps=int(g["n_steps"]), inference_cfg_rate=0.7, noise=_t(g, "noise"))
+    ref = _t(g, "mel")
+    assert mel.shape == ref.shape == (1, 80, int(n * 1.72))
+    assert (mel - ref).abs().max().item() <= 5e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_weight_norm_checkpoint_spelling_loads(golden):
+    """A checkpoint that still carries weight_g / weight_v (as s2mel.pth does) folds to the same tensors."""
+    g = golden("s2mel_tiny.npz")
+    m, cfg = _model(g)
+    W = S2.make_s2mel_weights(cfg, seed=int(g["seed"]))
+    sd = {}
+    for k, v in W.items():
+        if k.endswith("conv.conv.weight") or k.endswith("final_layer.linear.weight"):
+            sd[k[:-6] + "weight_g"] = v.reshape(v.shape[0], -1).norm(dim=1).reshape([-1] + [1] * (v.dim() - 1))
+            sd[k[:-6] + "weight_v"] = 3.0 * v
+        else:
+            sd[k] = v
+    m2 = S2.S2Mel(sd, cfg)
+    for k in W:
+        assert torch.allclose(m2.W[k], m.W[k], atol=1e-6), k

@@ -1,18 +1,10 @@
-timeout -k 10 300 python -m pytest tests/test_gpu_gpt.py -m gpu -x -q > gpurun_out/t.log 2>&1; tail -2 gpurun_out/t.log
-timeout -k 10 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['rtf'], d['stage_ms_per_step'])"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for P in 137 1200; do
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pt$P -- python tools/prof_gpt.py bf16 2 $P 40 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ps2 -- python tools/prof_s2mel.py 5 > gpurun_out/ps2.log 2>&1
+rm -f gpurun_out/ps2/*/*kernel_trace.csv
 python - <<PY
-import csv,glob,statistics,collections
-f=glob.glob('gpurun_out/pt$P/*/*kernel_trace.csv')[0]
-d=collections.defaultdict(list)
-for r in csv.DictReader(open(f)):
-    d[r['Kernel_Name'][:90]].append(int(r['End_Timestamp'])-int(r['Start_Timestamp']))
-for k,v in d.items():
-    if 'attn_decode' in k:
-        v=v[-600:]
-        print(f"P=$P {k[12:70]:60s} med={statistics.median(v)/1e3:7.2f}us min={min(v)/1e3:7.2f}")
+import csv,glob
+f=glob.glob('gpurun_out/ps2/*/*kernel_stats.csv')[0]
+for r in list(csv.DictReader(open(f)))[:14]:
+    print(f"{r['Name'][:100]:100s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:10.1f}us {float(r['TotalDurationNs'])/1e6:9.1f}ms {r['Percentage']:>6s}%")
 PY
-rm -rf gpurun_out/pt$P
-done
+grep s2mel gpurun_out/ps2.log

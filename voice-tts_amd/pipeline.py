@@ -128,6 +128,21 @@ class HotPath:
         codes = torch.as_tensor(np.asarray(codes), dtype=torch.int32, device=self.device)
         return self.gpt.latent(prefix, codes)
 
+    # ------------------------------------------------------------------ N1 (PyTorch glue, optional)
+    def attach_s2mel(self, W, cfg=None):
+        """Semantic-to-mel stage (length regulator + CFM/DiT) as PyTorch-ROCm glue on this device (voice-tts_amd/s2mel.py)."""
+        from .s2mel import S2MEL_CFG, S2Mel
+
+        self.s2mel_model = S2Mel(W, S2MEL_CFG if cfg is None else cfg, device=self.device)
+        return self
+
+    def s2mel(self, latent, codes, prompt_condition, ref_mel, style, n_timesteps=25, inference_cfg_rate=0.7, noise=None):
+        """infer_v2.py:713-731: latent [n,D] + codes [n] -> mel [1,80,floor(1.72 n)] (fp32, as the reference runs this stage)."""
+        codes = torch.as_tensor(np.asarray(codes), dtype=torch.long, device=self.device).reshape(1, -1)
+        lens = torch.tensor([codes.shape[1]], device=self.device)
+        return self.s2mel_model(latent.reshape(1, codes.shape[1], -1), codes, lens, prompt_condition, ref_mel, style,
+                                n_timesteps=n_timesteps, inference_cfg_rate=inference_cfg_rate, noise=noise)
+
     # ------------------------------------------------------------------ V0-V5
     def vocode(self, mel):
         """bigvgan(mel.float()) then the PCM clamp of infer_v2.py:735-744: returns fp32 [1, T] scaled to +-32767."""
