@@ -263,10 +263,24 @@ def main():
         tc = time.perf_counter()
         OV.bigvgan_forward(mels[0][:, :, :f_s].cpu(), Wb)
         t_frame = (time.perf_counter() - tc) / f_s
-        est = n_seg * (t_prefill + n_codes * t_step + (P + n_codes + 2) * t_lat_row + frames * t_frame)
+        t_s2 = 0.0
+        s2_note = ""
+        if use_s2mel:
+            # the s2mel glue is plain torch: its CPU leg is the same code on host tensors, 1 Euler step of the 25
+            import voice_tts_amd.s2mel as S2
+
+            cpu_s2 = S2.S2Mel(S2.make_s2mel_weights(S2.S2MEL_CFG, seed=1234), S2.S2MEL_CFG, device="cpu")
+            lat_c = torch.randn(1, n_codes, D, generator=g)
+            tc = time.perf_counter()
+            cpu_s2(lat_c, torch.randint(0, 8192, (1, n_codes), generator=g), torch.tensor([n_codes]), prompt_condition.cpu(), ref_mel.cpu(),
+                   style.cpu(), n_timesteps=1)
+            t_s2 = (time.perf_counter() - tc) * 25
+            s2_note = f", s2mel 1 of 25 Euler steps at T={Tref + frames} ({t_s2 / 25:.2f} s/step)"
+            log(f"cpu s2mel {t_s2 / 25:.2f} s/step")
+        est = n_seg * (t_prefill + n_codes * t_step + (P + n_codes + 2) * t_lat_row + t_s2 + frames * t_frame)
         cpu = {"value": round(audio_s / est, 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
                "sample": f"oracle fp32: 1 prefill of {P} rows ({t_prefill:.2f}s), {n_dec} decode steps ({t_step*1e3:.1f} ms/step), "
-                         f"latent pass on {n_lat} codes ({t_lat_row*1e3:.2f} ms/row), BigVGAN {f_s} frames ({t_frame*1e3:.1f} ms/frame); "
+                         f"latent pass on {n_lat} codes ({t_lat_row*1e3:.2f} ms/row), BigVGAN {f_s} frames ({t_frame*1e3:.1f} ms/frame){s2_note}; "
                          f"extrapolated linearly to the full request ({est:.0f}s est.)",
                "rtf": round(est / audio_s, 3)}
 
