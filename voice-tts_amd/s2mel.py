@@ -170,15 +170,15 @@ class S2Mel:
             n = self.head_dim
             freqs = 1.0 / (10000.0 ** (torch.arange(0, n, 2)[: n // 2].float() / n))
             ang = torch.outer(torch.arange(max(T, 64)).float(), freqs)
-            self._rope = torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1).to(self.device)
+            self._rope = torch.polar(torch.ones_like(ang), ang).to(self.device)  # complex64 [T, d/2]
         return self._rope[:T]
 
     @staticmethod
-    def _rotary(x, fc):  # x [B,T,h,d], fc [T,d/2,2]
-        xs = x.float().reshape(*x.shape[:-1], -1, 2)
-        fc = fc.view(1, xs.size(1), 1, xs.size(3), 2)
-        out = torch.stack([xs[..., 0] * fc[..., 0] - xs[..., 1] * fc[..., 1], xs[..., 1] * fc[..., 0] + xs[..., 0] * fc[..., 1]], -1)
-        return out.flatten(3)
+    def _rotary(x, fc):
+        """apply_rotary_emb (gpt_fast/model.py:348-360): (x0 + i x1) * (cos + i sin) on interleaved pairs, as one
+        complex multiply.  x [B,T,h,d] fp32, fc complex [T,d/2]."""
+        xc = torch.view_as_complex(x.reshape(*x.shape[:-1], -1, 2))
+        return torch.view_as_real(xc * fc.view(1, fc.shape[0], 1, fc.shape[1])).flatten(3)
 
     def _ada_norm(self, x, c, prefix):
         """AdaptiveLayerNorm(RMSNorm): weight * (rms(x) * g) + bias with (weight, bias) = project_layer(c)."""
@@ -186,8 +186,8 @@ class S2Mel:
         wb = _lin(c, W, prefix + ".project_layer")
         H = x.shape[-1]
         w, b = wb[..., :H], wb[..., H:]
-        n = x * torch.rsqrt(torch.mean(x * x, dim=-1, keepdim=True) + 1e-5) * W[prefix + ".norm.weight"]
-        return w * n + b
+        n = F.rms_norm(x, (H,), W[prefix + ".norm.weight"], 1e-5)
+        return torch.addcmul(b, w, n)
 
     def _transformer(self, x, c, mask):
         W, cfg = self.W, self.cfg
