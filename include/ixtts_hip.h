@@ -51,6 +51,17 @@ int ixtts_aa_snake_f32(const float* x_dev, float* y_dev, const float* up12_dev, 
                        const float* log_alpha_dev, const float* log_beta_dev, int B, int C, int T, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Row N1 helper -- full (unmasked, non-causal) fp32 attention of the s2mel DiT
+ * replaces: `F.scaled_dot_product_attention(q, k, v, attn_mask=mask)` with an all-true mask
+ *   indextts/s2mel/modules/gpt_fast/model.py:303 (called from diffusion_transformer.py:238)
+ * q, k, v, out: fp32, element (b, t, h, d) at base[b*stride_b + t*stride_t + h*stride_h + d] (d contiguous,
+ * head_dim 64, strides in floats and multiples of 4); out = softmax(scale * q k^T) v per (b, h).
+ */
+int ixtts_attn_full_f32(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, int B, int H, int T,
+                        int head_dim, long stride_b, long stride_t, long stride_h, long ostride_b, long ostride_t,
+                        long ostride_h, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Seam 2 -- BigVGAN-v2 generator
  * replaces: `BigVGAN.__init__/remove_weight_norm/forward`
  *   indextts/s2mel/modules/bigvgan/bigvgan.py:266-400 ; call site indextts/infer_v2.py:154-158,735

@@ -1,0 +1,172 @@
+// attn_full.hip -- full (non-causal, unmasked) multi-head attention in exact fp32 on the fp32 matrix cores of
+// gfx950, for the s2mel DiT (row N1): 25 Euler steps x 13 layers x (batch 2 x 8 heads) x T ~ 2300 x d = 64.
+//
+// Reference op: F.scaled_dot_product_attention(q, k, v, attn_mask=all-true) in
+// indextts/s2mel/modules/gpt_fast/model.py:303 (fp32: the reference runs s2mel without autocast, infer_v2.py:710-711).
+//
+// Flash-style, no S x S matrix, and NO transposes / LDS round trip between the two products:
+//   S^T = K Q^T   (v_mfma_f32_32x32x2_f32; rows = keys, cols = queries) leaves, in accumulator register r of lane l,
+//                 the score of query (l & 31) against key  (r&3) + 8*(r>>2) + 4*(l>>5).
+//   O^T += V^T P^T  sums over keys; the MFMA B operand of k-step r is B[k = l>>5][j = l&31] = P^T[key pair of r][query]
+//                 -- exactly that accumulator register.  The A operand V^T[d][key] is read from the V tile in LDS.
+// Every lane owns ONE query column: the online-softmax max/sum/rescale are per-lane scalars (+ one exchange with
+// lane^32, which holds the other half of the keys).  One workgroup = 2 waves = 64 queries; K/V tiles of 64 keys in LDS.
+//
+// Roofline: 4*T^2*d flops per head (fp32 MFMA peak 157.3 TFLOP/s); K/V re-read T/64 times from L2 (1.2 MB per head).
+#include "common.h"
+
+namespace ixtts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int AF_D = 64;        // head dim
+constexpr int AF_KT = 64;       // keys per tile
+constexpr int AF_QW = 32;       // queries per wave
+constexpr int AF_WAVES = 2;
+constexpr int AF_KP = AF_D + 1;  // K tile pitch (floats): lanes of a half-wave read 32 different keys -> odd pitch
+
+struct AttnFullArgs {
+  const float* q;  // element (b, t, h, d) at q[b*sb + t*st + h*sh + d]
+  const float* k;
+  const float* v;
+  float* o;        // same strides as q (separate base)
+  long sb, st, sh;       // q/k/v strides in floats
+  long osb, ost, osh;    // output strides
+  int B, H, T;
+  float scale;
+};
+
+__global__ __launch_bounds__(AF_WAVES * 64) void attn_full_f32_kernel(AttnFullArgs a) {
+  __shared__ float Ks[AF_KT * AF_KP];
+  __shared__ float Vs[AF_KT * AF_D];
+  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int q0 = blockIdx.x * (AF_WAVES * AF_QW) + wave * AF_QW;
+  const float* qb = a.q + b * a.sb + h * a.sh;
+  const float* kb = a.k + b * a.sb + h * a.sh;
+  const float* vb = a.v + b * a.sb + h * a.sh;
+
+  // Q^T as the B operand of S^T = K Q^T: lane holds Q[query l31][d = 2*kk + lh], pre-scaled
+  float qr[AF_D / 2];
+  {
+    const int qi = min(q0 + l31, a.T - 1);
+    const float* qp = qb + (long)qi * a.st + lh;
+    // scores are kept in the log2 domain (q pre-scaled by scale * log2 e): softmax weights are one v_exp_f32 each
+    const float qs = a.scale * 1.4426950408889634f;
+#pragma unroll
+    for (int kk = 0; kk < AF_D / 2; ++kk) qr[kk] = qp[2 * kk] * qs;
+  }
+  f32x16 ot[2];  // O^T tiles: d 0..31, 32..63 (rows d in registers, column = this lane's query)
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[j][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  for (int t0 = 0; t0 < a.T; t0 += AF_KT) {
+    __syncthreads();
+    // stage K and V tiles (64 keys x 64 dims): each thread moves 8 float4 of each
+#pragma unroll
+    for (int i = 0; i < (AF_KT * AF_D / 4) / (AF_WAVES * 64); ++i) {
+      const int idx = threadIdx.x + i * (AF_WAVES * 64);
+      const int key = idx >> 4, c4 = idx & 15;
+      const int t = t0 + key;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < a.T) {
+        kv = *reinterpret_cast<const float4*>(kb + (long)t * a.st + c4 * 4);
+        vv = *reinterpret_cast<const float4*>(vb + (long)t * a.st + c4 * 4);
+      }
+      float* kd = Ks + key * AF_KP + c4 * 4;
+      kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+      *reinterpret_cast<float4*>(Vs + key * AF_D + c4 * 4) = vv;
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T for the two 32-key halves of the tile
+    f32x16 st[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[j][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < AF_D / 2; ++kk) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float ka = Ks[(j * 32 + l31) * AF_KP + 2 * kk + lh];  // A[i = key][k = d]
+        st[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka, qr[kk], st[j], 0, 0, 0);
+      }
+    }
+    // ---- online softmax for this lane's query; keys beyond T are masked
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (key >= a.T) st[j][r] = -INFINITY;
+        tmax = fmaxf(tmax, st[j][r]);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mn = fmaxf(m, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);  // 0 on the first tile (m = -inf)
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(st[j][r] - mn);
+        st[j][r] = p;
+        psum += p;
+      }
+    psum += __shfl_xor(psum, 32, 64);
+    l = l * alpha + psum;
+    m = mn;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[j][r] *= alpha;
+    // ---- O^T += V^T P^T : k-step (j, r) pairs key (r&3)+8(r>>2) [lanes 0-31] with that key + 4 [lanes 32-63]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float* vrow = Vs + key * AF_D + l31;  // A[i = d][k = key]
+        const float pv = st[j][r];                  // B[k = key][j = query]
+        ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], pv, ot[0], 0, 0, 0);
+        ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], pv, ot[1], 0, 0, 0);
+      }
+  }
+  // ---- normalise and store: lane's query column, d rows in registers
+  const int qi = q0 + l31;
+  if (qi < a.T) {
+    const float inv = 1.0f / l;
+    float* op = a.o + b * a.osb + (long)qi * a.ost + h * a.osh;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) op[j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = ot[j][r] * inv;
+  }
+}
+
+}  // namespace ixtts
+
+extern "C" int ixtts_attn_full_f32(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, int B, int H, int T,
+                                   int head_dim, long stride_b, long stride_t, long stride_h, long ostride_b, long ostride_t,
+                                   long ostride_h, float scale, void* stream) {
+  using namespace ixtts;
+  IX_ARG(q_dev && k_dev && v_dev && out_dev, "attn_full: null pointer");
+  IX_ARG(head_dim == AF_D, "attn_full: head_dim %d (only 64 is built)", head_dim);
+  IX_ARG(B > 0 && H > 0 && T > 0 && (long)B * H <= 65535, "attn_full: bad shape B=%d H=%d T=%d", B, H, T);
+  IX_ARG(stride_t % 4 == 0 && stride_h % 4 == 0 && stride_b % 4 == 0, "attn_full: strides must keep 16-byte row alignment");
+  AttnFullArgs a;
+  a.q = q_dev; a.k = k_dev; a.v = v_dev; a.o = out_dev;
+  a.sb = stride_b; a.st = stride_t; a.sh = stride_h;
+  a.osb = ostride_b; a.ost = ostride_t; a.osh = ostride_h;
+  a.B = B; a.H = H; a.T = T; a.scale = scale;
+  dim3 grid(ceil_div(T, AF_WAVES * AF_QW), B * H);
+  hipLaunchKernelGGL(attn_full_f32_kernel, grid, dim3(AF_WAVES * 64), 0, (hipStream_t)stream, a);
+  IX_HIP(hipGetLastError());
+  return IXTTS_OK;
+}

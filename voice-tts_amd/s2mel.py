@@ -116,6 +116,26 @@ def _pad_reflect(x, left, right):
     return y[..., : y.shape[-1] - extra]
 
 
+def attn_full(q, k, v, scale=None):
+    """softmax(scale * q k^T) v for q, k, v [B, T, h, 64] fp32 CUDA tensors (any strides with d contiguous) through
+    libixtts_hip.so's fp32-MFMA flash kernel (csrc/attn_full.hip); returns [B, T, h, 64] contiguous."""
+    import ctypes as C
+
+    from . import _lib
+
+    B, T, Hh, d = q.shape
+    assert d == 64 and q.is_cuda and q.dtype == torch.float32 and k.shape == q.shape and v.shape == q.shape
+    for t in (q, k, v):
+        assert t.stride(3) == 1 and t.stride() == q.stride()
+    out = torch.empty(B, T, Hh, d, device=q.device, dtype=torch.float32)
+    sc = float(scale if scale is not None else 1.0 / math.sqrt(d))
+    with torch.cuda.device(q.device):
+        rc = _lib.lib().ixtts_attn_full_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Hh, T, d, q.stride(0), q.stride(1),
+                                            q.stride(2), out.stride(0), out.stride(1), out.stride(2), C.c_float(sc), _lib.current_stream_ptr())
+    _lib.check(rc, "ixtts_attn_full_f32")
+    return out
+
+
 def _lin(x, W, name):
     return F.linear(x, W[name + ".weight"], W.get(name + ".bias"))
 
@@ -202,11 +222,15 @@ class S2Mel:
                 x = _lin(torch.cat([x, skips.pop()], dim=-1), W, p + "skip_in_linear")
             a = self._ada_norm(x, c, p + "attention_norm")
             q, k, v = F.linear(a, W[p + "attention.wqkv.weight"]).split([H, H, H], dim=-1)
-            q = self._rotary(q.view(B, T, nh, hd), fc).transpose(1, 2)
-            k = self._rotary(k.view(B, T, nh, hd), fc).transpose(1, 2)
-            v = v.view(B, T, nh, hd).transpose(1, 2)
-            y = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=0.0)
-            h = x + F.linear(y.transpose(1, 2).reshape(B, T, H), W[p + "attention.wo.weight"])
+            q = self._rotary(q.view(B, T, nh, hd), fc)
+            k = self._rotary(k.view(B, T, nh, hd), fc)
+            v = v.reshape(B, T, nh, hd)
+            if mask is None and hd == 64 and x.is_cuda:
+                y = attn_full(q.contiguous(), k.contiguous(), v.contiguous()).reshape(B, T, H)  # HIP fp32-MFMA flash kernel
+            else:
+                y = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=mask, dropout_p=0.0)
+                y = y.transpose(1, 2).reshape(B, T, H)
+            h = x + F.linear(y, W[p + "attention.wo.weight"])
             f = self._ada_norm(h, c, p + "ffn_norm")
             x = h + F.linear(F.silu(F.linear(f, W[p + "feed_forward.w1.weight"])) * F.linear(f, W[p + "feed_forward.w3.weight"]), W[p + "feed_forward.w2.weight"])
             if i < L // 2:
