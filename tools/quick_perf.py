@@ -42,7 +42,7 @@ if "gpt" in what:
     t0 = time.time()
     W = WR.make_gpt_weights(WR.GPT_CFG, seed=1234)
     print(f"gpt weights {time.time()-t0:.1f}s", flush=True)
-    for dtype in ("bf16", "f32"):
+    for dtype in (("bf16",) if "bf16only" in what else ("bf16", "f32")):
         for B in (1, 2):
             t0 = time.time()
             eng = GptEngine(WR.GPT_CFG, dtype=dtype, max_seq=2048, max_batch=B, device=dev).load_state_dict(W)
@@ -65,7 +65,7 @@ if "gpt" in what:
 if "micro" in what:
     # per-kernel cost inside a graph, un-profiled: 24 layers x kind, replayed
     W = WR.make_gpt_weights(WR.GPT_CFG, seed=1234)
-    for dtype in ("bf16", "f32"):
+    for dtype in (("bf16",) if "bf16only" in what else ("bf16", "f32")):
         eng = GptEngine(WR.GPT_CFG, dtype=dtype, max_seq=2048, max_batch=2, device=dev).load_state_dict(W)
         emb = torch.randn(136, 1280, generator=torch.Generator().manual_seed(1)) * 0.5
         eng.prefill(0, emb, 0)

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libixtts_hip.so")
+LIB_PATH = os.environ.get("IXTTS_LIB") or os.path.join(HERE, "libixtts_hip.so")  # IXTTS_LIB: developer builds (trace)
 
 MAX_STAGES = 8
 MAX_RESK = 4

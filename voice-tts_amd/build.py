@@ -15,8 +15,14 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libixtts_hip.so")
 OBJ = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+TRACE = os.environ.get("IXTTS_TRACE") == "1"  # developer timeline build (tools/trace_decode.py): separate library
+if TRACE:
+    LIB = os.path.join(HERE, "libixtts_hip_trace.so")
+    OBJ = os.path.join(HERE, "build_trace")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-result", "-Wno-unused-value", "-fno-gpu-rdc"]
+         "-Wno-unused-result", "-Wno-unused-value", "-fno-gpu-rdc",
+         # first 16 kernarg dwords arrive in SGPRs with the wave (no s_load round trip before the first global loads)
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"] + (["-DIXTTS_TRACE"] + os.environ.get("IXTTS_EXP", "").split() if TRACE else [])
 
 
 def _sources():

@@ -21,18 +21,25 @@
 using namespace ixtts;
 
 // ------------------------------------------------------------------------------------ launch helpers
-template <typename WT, typename KVT, int K, int ROWS, int UNITS, int B, int INP, int EPI>
+#ifdef IXTTS_TRACE
+static int g_trace_seq = 0;  // one id per traced launch (baked into captured graphs)
+#define IXTTS_TRACE_ARG , g_trace_seq++
+#else
+#define IXTTS_TRACE_ARG
+#endif
+template <typename WT, typename KVT, int K, int ROWS, int UNITS, int B, int INP, int EPI, int WPB = 4, bool XLDS = false>
 static int launch_gemv(const GemvArgs& a, hipStream_t st) {
-  auto kern = gemv_reg_kernel<WT, K, ROWS, UNITS, B, INP, EPI, KVT>;
+  auto kern = gemv_reg_kernel<WT, K, ROWS, UNITS, B, INP, EPI, KVT, WPB, XLDS>;
   const int n_units = (a.N + ROWS - 1) / ROWS;
-  const int grid = ceil_div(n_units, 4 * UNITS);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a);
+  const int grid = ceil_div(n_units, WPB * UNITS);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), 0, st, a.wt, a.xin, a.bias, a.out, a.N, a.slot0, a.out_stride, a.smax, a.kcache, a.vcache,
+                     a.cur_len, a.heads, a.nsplit, a.ln_w, a.ln_b IXTTS_TRACE_ARG);
   return IXTTS_OK;
 }
 
-template <typename WT, typename KVT, int K, int ROWS, int UNITS, int B, int EPI>
+template <typename WT, typename KVT, int K, int ROWS, int UNITS, int B, int EPI, int WPB = 4>
 static int launch_gemv_lds(const GemvArgs& a, hipStream_t st) {
-  auto kern = gemv_lds_kernel<WT, K, ROWS, UNITS, B, EPI, KVT>;
+  auto kern = gemv_lds_kernel<WT, K, ROWS, UNITS, B, EPI, KVT, WPB>;
   const size_t smem = (size_t)B * K * sizeof(float);
   if (smem > 64 * 1024) {
     static bool done = false;
@@ -42,8 +49,9 @@ static int launch_gemv_lds(const GemvArgs& a, hipStream_t st) {
     }
   }
   const int n_units = (a.N + ROWS - 1) / ROWS;
-  const int grid = ceil_div(n_units, 4 * UNITS);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, a);
+  const int grid = ceil_div(n_units, WPB * UNITS);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), smem, st, a.wt, a.xin, a.bias, a.out, a.N, a.slot0, a.out_stride, a.smax, a.kcache,
+                     a.vcache, a.cur_len, a.heads, a.nsplit, a.ln_w, a.ln_b IXTTS_TRACE_ARG);
   return IXTTS_OK;
 }
 
@@ -66,7 +74,7 @@ static int gemv_qkv(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.cur_len = h->cur_len;
   a.smax = h->smax;
   a.heads = h->H;
-  return launch_gemv<WT, KVT, D, DM::R1, DM::U_QKV, B, IN_LN, EPI_QKV>(a, st);
+  return launch_gemv<WT, KVT, D, DM::R1, DM::U_QKV, B, IN_LN, EPI_QKV, 4, DM::XLDS>(a, st);
 }
 
 template <typename WT, typename KVT, int D, int B>
@@ -105,7 +113,7 @@ static int gemv_fc(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.xin = h->h;
   a.out = h->ff;
   a.out_stride = 4 * D;
-  return launch_gemv<WT, KVT, D, DM::R1, DM::U_FC, B, IN_LN, EPI_GELU>(a, st);
+  return launch_gemv<WT, KVT, D, DM::R1, DM::U_FC, B, IN_LN, EPI_GELU, DM::W_FC, DM::XLDS>(a, st);
 }
 
 template <typename WT, typename KVT, int D, int B>
@@ -121,7 +129,7 @@ static int gemv_pr(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.xin = h->ff;
   a.out = h->h;
   a.out_stride = D;
-  return launch_gemv_lds<WT, KVT, 4 * D, DM::R4, DM::U_PR, B, EPI_RESID>(a, st);
+  return launch_gemv_lds<WT, KVT, 4 * D, DM::R4, DM::U_PR, B, EPI_RESID, DM::W_PR>(a, st);
 }
 
 template <typename WT, typename KVT, int D, int B>
@@ -161,8 +169,10 @@ static int forward_layers(ixtts_gpt* h, int slot0, hipStream_t st) {
     t.D = D;
     // measured r01 (B=2, bf16): 8 waves x 4 row-groups in flight is the best compromise between the
     // speculative first pass at short context (5.4 us at S=160) and the stream at long context (12.6 us at S=1220)
-    if (t.nsplit > 1) hipLaunchKernelGGL((attn_decode_kernel<KVT, 4, 8>), dim3(h->H, t.nsplit, B), dim3(256), 0, st, t);
-    else hipLaunchKernelGGL((attn_decode_kernel<KVT, 8, 4>), dim3(h->H, 1, B), dim3(512), 0, st, t);
+    if (t.nsplit > 1) hipLaunchKernelGGL((attn_decode_kernel<KVT, 4, 8>), dim3(h->H, t.nsplit, B), dim3(256), 0, st, t.q, t.kcache, t.vcache, t.cur_len,
+                                          t.valid_from, t.smax, t.heads, t.slot0, t.D, t.out, t.nsplit IXTTS_TRACE_ARG);
+    else hipLaunchKernelGGL((attn_decode_kernel<KVT, 8, 4>), dim3(h->H, 1, B), dim3(512), 0, st, t.q, t.kcache, t.vcache, t.cur_len, t.valid_from,
+                            t.smax, t.heads, t.slot0, t.D, t.out, t.nsplit IXTTS_TRACE_ARG);
     IX_TRY((gemv_out<WT, KVT, D, B>(h, l, slot0, st)));
     IX_TRY((gemv_fc<WT, KVT, D, B>(h, l, slot0, st)));
     IX_TRY((gemv_pr<WT, KVT, D, B>(h, l, slot0, st)));
@@ -819,3 +829,26 @@ extern "C" int ixtts_gpt_destroy(ixtts_gpt* h) {
   delete h;
   return IXTTS_OK;
 }
+
+#ifdef IXTTS_TRACE
+// developer timeline hooks (trace builds only; not part of include/ixtts_hip.h)
+extern "C" int ixtts_trace_begin(void) {  // allocate (first call) and clear the record table
+  unsigned long long* buf = nullptr;
+  const size_t bytes = (size_t)TRACE_SLOTS * TRACE_WGS * 64;
+  IX_HIP(hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_trace), sizeof(buf)));
+  if (!buf) {
+    IX_HIP(hipMalloc(&buf, bytes));
+    IX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)));
+  }
+  IX_HIP(hipMemset(buf, 0, bytes));
+  IX_HIP(hipDeviceSynchronize());
+  return IXTTS_OK;
+}
+extern "C" int ixtts_trace_read(unsigned long long* host) {  // host: TRACE_SLOTS * TRACE_WGS * 8 u64
+  IX_HIP(hipDeviceSynchronize());
+  unsigned long long* buf = nullptr;
+  IX_HIP(hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_trace), sizeof(buf)));
+  IX_HIP(hipMemcpy(host, buf, (size_t)TRACE_SLOTS * TRACE_WGS * 64, hipMemcpyDeviceToHost));
+  return IXTTS_OK;
+}
+#endif

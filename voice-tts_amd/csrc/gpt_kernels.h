@@ -24,6 +24,46 @@ namespace ixtts {
 
 constexpr int HD = 64;  // head dim (asserted at create)
 
+// Developer timeline (IXTTS_TRACE builds only, see tools/trace_decode.py): wave 0 of every workgroup records
+// {kernel id, block, wall clock at entry / after the dot products / at exit} (100 MHz constant clock).
+#ifdef IXTTS_TRACE
+constexpr int TRACE_SLOTS = 2048, TRACE_WGS = 512;  // launches (modulo) x workgroups per launch
+static __device__ unsigned long long* g_trace = nullptr;
+// wall clock read that cannot move above the computation of `dep` (and, being volatile, keeps its order)
+__device__ __forceinline__ long long clock_after(float dep) {
+  long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+  return t;
+}
+struct TraceScope {
+  long long t0, ta, tb;
+  int kid, seq;
+  __device__ __forceinline__ TraceScope(int kernel_id, int launch_seq) : ta(0), tb(0), kid(kernel_id), seq(launch_seq) { t0 = clock_after(0.f); }
+  __device__ __forceinline__ void inputs(float dep) { ta = clock_after(dep); }  // activations have arrived
+  __device__ __forceinline__ void mid(float dep) { tb = clock_after(dep); }     // weights / keys have arrived and are reduced
+  __device__ __forceinline__ void end() {
+    const unsigned int blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (threadIdx.x == 0 && g_trace && blk < TRACE_WGS) {
+      const long long t2 = clock_after(0.f);
+      unsigned long long* r = g_trace + ((size_t)(seq % TRACE_SLOTS) * TRACE_WGS + blk) * 8;
+      r[0] = ((unsigned long long)(kid + 1) << 32) | (unsigned int)seq;
+      r[1] = t0; r[2] = ta ? ta : t0; r[3] = tb ? tb : t2; r[4] = t2;
+    }
+  }
+};
+#define IXTTS_TRACE_PARAM , int trace_seq
+#define IXTTS_TRACE_SEQ trace_seq
+#else
+struct TraceScope {
+  __device__ __forceinline__ TraceScope(int, int) {}
+  __device__ __forceinline__ void inputs(float) {}
+  __device__ __forceinline__ void mid(float) {}
+  __device__ __forceinline__ void end() {}
+};
+#define IXTTS_TRACE_PARAM
+#define IXTTS_TRACE_SEQ 0
+#endif
+
 enum { IN_LN = 0, IN_LN2 = 1, IN_PLAIN = 2, IN_ATTN = 3, IN_ATTN2 = 4, IN_ATTN4 = 5 };  // IN_ATTNn: split-S merge, n compile-time
 
 // split-S attention partials: per (slot, head, split) [m, l, pad, pad, acc[64]] (acc 16-byte aligned)
@@ -119,8 +159,20 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int lane, int u
 
 // ------------------------------------------------------------------------------------
 // Register-resident GEMV (K = model_dim kernels: QKV, out-proj, FC, head).
-template <typename WT, int K, int ROWS, int UNITS, int B, int INP, int EPI, typename KVT>
-__global__ __launch_bounds__(256) void gemv_reg_kernel(GemvArgs a) {
+// XLDS: the activation rows reach the waves through LDS (one global read per workgroup) instead of every wave
+// reading its ROWS copies from L2 -- with 5 waves x 2 rows that private traffic through the CU's L1 was twice the
+// weight stream itself (r01 timeline: activations ready 3.1 us after entry, weights reduced at 4.3 us).
+template <typename WT, int K, int ROWS, int UNITS, int B, int INP, int EPI, typename KVT, int WPB = 4, bool XLDS = false>
+__global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, const float* xin, const float* bias, float* out, int N, int slot0, int out_stride, int smax,
+                                                        void* kcache, void* vcache, const int* cur_len, int heads, int nsplit,
+                                                        const float* ln_w, const float* ln_b IXTTS_TRACE_PARAM) {
+  // scalar kernel arguments (not a by-value struct): the first 16 dwords are preloaded into SGPRs at wave launch
+  // (-amdgpu-kernarg-preload-count), so the first loads do not wait for a kernarg round trip
+  GemvArgs a;
+  a.wt = wt; a.xin = xin; a.bias = bias; a.out = out; a.N = N; a.slot0 = slot0; a.out_stride = out_stride; a.smax = smax;
+  a.kcache = kcache; a.vcache = vcache; a.cur_len = cur_len; a.heads = heads; a.nsplit = nsplit; a.ln_w = ln_w; a.ln_b = ln_b;
+  a.norm_out = nullptr;
+  TraceScope trace(EPI, IXTTS_TRACE_SEQ);
   constexpr int VEC = WVec<WT>::VEC;
   constexpr int PER = 64 * VEC;       // elements per wave-load
   constexpr int NL = ROWS * K / PER;  // loads per lane per unit
@@ -129,13 +181,23 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(GemvArgs a) {
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int unit0 = (blockIdx.x * 4 + wave) * UNITS;
+  const int unit0 = (blockIdx.x * WPB + wave) * UNITS;  // WPB waves per workgroup: chosen so the grid is one WG per CU
   const int n_units = (a.N + ROWS - 1) / ROWS;
-  if (unit0 >= n_units) return;  // wave-uniform; no barriers in this kernel
+  if (!XLDS && unit0 >= n_units) return;  // wave-uniform; the non-XLDS kernel has no barriers
 
   // ---- 1. activation slice -> registers (L2-resident, issued first: vmcnt retires in order)
   float xr[B][NL][VEC];
-  if constexpr (INP == IN_ATTN || INP == IN_ATTN2 || INP == IN_ATTN4) {
+  constexpr int X4 = B * K / 4, NT = 64 * WPB, XV = (X4 + NT - 1) / NT;  // XLDS: float4 per thread
+  float4 xstage[XLDS ? XV : 1];
+  if constexpr (XLDS) {
+    static_assert(INP == IN_LN || INP == IN_LN2 || INP == IN_PLAIN, "XLDS stages plain activation rows");
+    const float* xbase = a.xin + (size_t)a.slot0 * K;  // slots are contiguous rows
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int idx = threadIdx.x + i * NT;
+      xstage[i] = (X4 % NT == 0 || idx < X4) ? *reinterpret_cast<const float4*>(xbase + (size_t)idx * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else if constexpr (INP == IN_ATTN || INP == IN_ATTN2 || INP == IN_ATTN4) {
     constexpr int NSP = INP == IN_ATTN2 ? 2 : (INP == IN_ATTN4 ? 4 : 0);  // 0: runtime a.nsplit
     const int nsp = NSP ? NSP : a.nsplit;
     // flash-decode merge of the split-S partials, straight into the lane's slice:
@@ -216,36 +278,60 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(GemvArgs a) {
       }
     }
   }
+  // sched_barrier(0): nothing crosses.  The issue order activations -> epilogue operands -> weights is the design
+  // (vmcnt retires in order, so the first consumer waits only for what it needs); left alone, the scheduler sinks the
+  // small loads to their use at the end of the kernel (a whole extra memory round trip) or batches the activation loads.
+  __builtin_amdgcn_sched_barrier(0);
   // ---- 2. epilogue operands of the rows this lane will write
+  // (every lane loads, indices clamped: a load under a branch forces a full vmcnt wait where the branch rejoins)
   float pre_bias[UNITS], pre_res[UNITS];
   int pre_pos = 0;
+  const int elane = min(lane, ROWS * B - 1);
 #pragma unroll
   for (int u = 0; u < UNITS; ++u) {
-    pre_bias[u] = 0.f;
+    const int n = min((unit0 + u) * ROWS + elane / B, a.N - 1);
+    pre_bias[u] = a.bias[n];
     pre_res[u] = 0.f;
-    if (lane < ROWS * B) {
-      const int n = (unit0 + u) * ROWS + lane / B;
-      if (n < a.N) {
-        pre_bias[u] = a.bias[n];
-        if constexpr (EPI == EPI_RESID) pre_res[u] = a.out[(size_t)(a.slot0 + lane % B) * a.out_stride + n];
-      }
-    }
+    if constexpr (EPI == EPI_RESID) pre_res[u] = a.out[(size_t)(a.slot0 + elane % B) * a.out_stride + n];
   }
-  if constexpr (EPI == EPI_QKV) {
-    if (lane < ROWS * B) pre_pos = a.cur_len[a.slot0 + lane % B];
-  }
+  if constexpr (EPI == EPI_QKV) pre_pos = a.cur_len[a.slot0 + elane % B];
+  __builtin_amdgcn_sched_barrier(0);
   // ---- 3. weight stream (HBM)
   uint4 wraw[UNITS][NL];
 #pragma unroll
   for (int u = 0; u < UNITS; ++u) {
+    // unconditional loads (addresses clamped, products of clamped elements dropped in step 5): a predicated load becomes a branch, and across
+    // branches the compiler's vmcnt bookkeeping degrades to "wait for everything" -- the activations, issued first,
+    // would then only be usable once the whole weight stream has landed (r01 timeline: 3.1 us instead of 1.5 us)
     const int unit = unit0 + u;
-    const WT* base = reinterpret_cast<const WT*>(a.wt) + (size_t)unit * ROWS * K;
-    const int rows_here = (unit < n_units) ? min(ROWS, a.N - unit * ROWS) : 0;
+    const int unit_c = min(unit, n_units - 1);
+    const WT* base = reinterpret_cast<const WT*>(a.wt) + (size_t)unit_c * ROWS * K;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int e = j * PER + lane * VEC;
-      wraw[u][j] = (e < rows_here * K) ? *reinterpret_cast<const uint4*>(base + e) : make_uint4(0u, 0u, 0u, 0u);
+      wraw[u][j] = *reinterpret_cast<const uint4*>(base + (e < min(ROWS, a.N - unit_c * ROWS) * K ? e : 0));
     }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (XLDS) {
+    __shared__ __attribute__((aligned(16))) float xsh[B * K];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int idx = threadIdx.x + i * NT;
+      if (X4 % NT == 0 || idx < X4) *reinterpret_cast<float4*>(xsh + idx * 4) = xstage[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const int k0 = (j * PER + lane * VEC) % K;
+#pragma unroll
+        for (int v4 = 0; v4 < VEC / 4; ++v4) {
+          const float4 t = *reinterpret_cast<const float4*>(xsh + b * K + k0 + v4 * 4);
+          xr[b][j][v4 * 4 + 0] = t.x; xr[b][j][v4 * 4 + 1] = t.y; xr[b][j][v4 * 4 + 2] = t.z; xr[b][j][v4 * 4 + 3] = t.w;
+        }
+      }
   }
   // ---- 4. LayerNorm in registers (gain/bias of the norm feeding the matrix are pre-folded)
   if constexpr (INP == IN_LN || INP == IN_LN2) {
@@ -290,6 +376,7 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(GemvArgs a) {
       }
     }
   }
+  trace.inputs(xr[0][0][0]);
   // ---- 5. dot products, DPP reduction, epilogue
 #pragma unroll
   for (int u = 0; u < UNITS; ++u) {
@@ -300,10 +387,11 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(GemvArgs a) {
     for (int r = 0; r < ROWS; ++r)
 #pragma unroll
       for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
+    const int rows_here = min(ROWS, a.N - unit * ROWS);
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int e = j * PER + lane * VEC;
-      const int row = e / K;
+      const int row = (e < rows_here * K) ? e / K : ROWS;  // ROWS: element beyond the matrix (its load was clamped)
       float wv[VEC];
       WVec<WT>::unpack(wraw[u][j], wv);
 #pragma unroll
@@ -320,15 +408,26 @@ __global__ __launch_bounds__(256) void gemv_reg_kernel(GemvArgs a) {
     for (int r = 0; r < ROWS; ++r)
 #pragma unroll
       for (int b = 0; b < B; ++b) tot[r][b] = wave_sum(acc[r][b]);
+    if (u == UNITS - 1) trace.mid(tot[0][0]);
     gemv_epilogue<K, ROWS, B, EPI, KVT>(a, lane, unit, tot, pre_bias[u], pre_res[u], pre_pos);
   }
+  trace.end();
 }
 
 // ------------------------------------------------------------------------------------
 // LDS-staged GEMV for the long-K matrix (MLP out, K = 4*model_dim): the activation vector
 // (20 KB per slot) is shared by the workgroup's 4 waves through LDS; one barrier.
-template <typename WT, int K, int ROWS, int UNITS, int B, int EPI, typename KVT>
-__global__ __launch_bounds__(256) void gemv_lds_kernel(GemvArgs a) {
+template <typename WT, int K, int ROWS, int UNITS, int B, int EPI, typename KVT, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void gemv_lds_kernel(const void* wt, const float* xin, const float* bias, float* out, int N, int slot0, int out_stride, int smax,
+                                                        void* kcache, void* vcache, const int* cur_len, int heads, int nsplit,
+                                                        const float* ln_w, const float* ln_b IXTTS_TRACE_PARAM) {
+  // scalar kernel arguments (not a by-value struct): the first 16 dwords are preloaded into SGPRs at wave launch
+  // (-amdgpu-kernarg-preload-count), so the first loads do not wait for a kernarg round trip
+  GemvArgs a;
+  a.wt = wt; a.xin = xin; a.bias = bias; a.out = out; a.N = N; a.slot0 = slot0; a.out_stride = out_stride; a.smax = smax;
+  a.kcache = kcache; a.vcache = vcache; a.cur_len = cur_len; a.heads = heads; a.nsplit = nsplit; a.ln_w = ln_w; a.ln_b = ln_b;
+  a.norm_out = nullptr;
+  TraceScope trace(4, IXTTS_TRACE_SEQ);
   constexpr int VEC = WVec<WT>::VEC;
   constexpr int PER = 64 * VEC;
   constexpr int NL = ROWS * K / PER;
@@ -337,50 +436,51 @@ __global__ __launch_bounds__(256) void gemv_lds_kernel(GemvArgs a) {
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int unit0 = (blockIdx.x * 4 + wave) * UNITS;
+  const int unit0 = (blockIdx.x * WPB + wave) * UNITS;
   const int n_units = (a.N + ROWS - 1) / ROWS;
 
   // activation vector: global -> registers (issued before the weight stream)
   constexpr int TOT4 = B * K / 4;
-  constexpr int XV = (TOT4 + 255) / 256;  // float4 per thread
+  constexpr int NT = 64 * WPB;
+  constexpr int XV = (TOT4 + NT - 1) / NT;  // float4 per thread
   const float* xbase = a.xin + (size_t)a.slot0 * K;  // slots are contiguous: [slot0 .. slot0+B) x K
   float4 xv[XV];
 #pragma unroll
   for (int i = 0; i < XV; ++i) {
-    const int idx = threadIdx.x + i * 256;
-    xv[i] = (TOT4 % 256 == 0 || idx < TOT4) ? *reinterpret_cast<const float4*>(xbase + (size_t)idx * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int idx = threadIdx.x + i * NT;
+    xv[i] = (TOT4 % NT == 0 || idx < TOT4) ? *reinterpret_cast<const float4*>(xbase + (size_t)idx * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  __builtin_amdgcn_sched_barrier(0);  // issue order: activations, epilogue operands, weights (see gemv_reg_kernel)
   float pre_bias[UNITS], pre_res[UNITS];
+  const int elane = min(lane, ROWS * B - 1);
 #pragma unroll
   for (int u = 0; u < UNITS; ++u) {
-    pre_bias[u] = 0.f;
+    const int n = min((unit0 + u) * ROWS + elane / B, a.N - 1);
+    pre_bias[u] = a.bias[n];
     pre_res[u] = 0.f;
-    if (lane < ROWS * B) {
-      const int n = (unit0 + u) * ROWS + lane / B;
-      if (n < a.N) {
-        pre_bias[u] = a.bias[n];
-        if constexpr (EPI == EPI_RESID) pre_res[u] = a.out[(size_t)(a.slot0 + lane % B) * a.out_stride + n];
-      }
-    }
+    if constexpr (EPI == EPI_RESID) pre_res[u] = a.out[(size_t)(a.slot0 + elane % B) * a.out_stride + n];
   }
+  __builtin_amdgcn_sched_barrier(0);
   uint4 wraw[UNITS][NL];
 #pragma unroll
   for (int u = 0; u < UNITS; ++u) {
-    const int unit = unit0 + u;
-    const WT* base = reinterpret_cast<const WT*>(a.wt) + (size_t)unit * ROWS * K;
-    const int rows_here = (unit < n_units) ? min(ROWS, a.N - unit * ROWS) : 0;
+    const int unit = unit0 + u;  // unconditional loads, see gemv_reg_kernel
+    const int unit_c = min(unit, n_units - 1);
+    const WT* base = reinterpret_cast<const WT*>(a.wt) + (size_t)unit_c * ROWS * K;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int e = j * PER + lane * VEC;
-      wraw[u][j] = (e < rows_here * K) ? *reinterpret_cast<const uint4*>(base + e) : make_uint4(0u, 0u, 0u, 0u);
+      wraw[u][j] = *reinterpret_cast<const uint4*>(base + (e < min(ROWS, a.N - unit_c * ROWS) * K ? e : 0));
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < XV; ++i) {
-    const int idx = threadIdx.x + i * 256;
-    if (TOT4 % 256 == 0 || idx < TOT4) *reinterpret_cast<float4*>(xs + idx * 4) = xv[i];
+    const int idx = threadIdx.x + i * NT;
+    if (TOT4 % NT == 0 || idx < TOT4) *reinterpret_cast<float4*>(xs + idx * 4) = xv[i];
   }
   __syncthreads();
+  trace.inputs(xv[0].x);
 
 #pragma unroll
   for (int u = 0; u < UNITS; ++u) {
@@ -391,11 +491,13 @@ __global__ __launch_bounds__(256) void gemv_lds_kernel(GemvArgs a) {
     for (int r = 0; r < ROWS; ++r)
 #pragma unroll
       for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
+    const int rows_here = min(ROWS, a.N - unit * ROWS);
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int e = j * PER + lane * VEC;
-      const int row = e / K;
-      const int k0 = e - row * K;
+      const int row0 = e / K;
+      const int k0 = e - row0 * K;
+      const int row = (e < rows_here * K) ? row0 : ROWS;  // ROWS: element beyond the matrix (its load was clamped)
       float wv[VEC];
       WVec<WT>::unpack(wraw[u][j], wv);
 #pragma unroll
@@ -419,8 +521,10 @@ __global__ __launch_bounds__(256) void gemv_lds_kernel(GemvArgs a) {
     for (int r = 0; r < ROWS; ++r)
 #pragma unroll
       for (int b = 0; b < B; ++b) tot[r][b] = wave_sum(acc[r][b]);
+    if (u == UNITS - 1) trace.mid(tot[0][0]);
     gemv_epilogue<K, ROWS, B, EPI, KVT>(a, lane, unit, tot, pre_bias[u], pre_res[u], 0);
   }
+  trace.end();
 }
 
 // ------------------------------------------------------------------------------------
@@ -605,7 +709,13 @@ __device__ __forceinline__ void load_q_slice(const float* qp, int dp, float (&qv
 }
 
 template <typename KVT, int NW, int IT>
-__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* q, const void* kcache, const void* vcache,
+                                                             const int* cur_len, const int* valid_from, int smax, int heads, int slot0,
+                                                             int D, float* out, int nsplit_ IXTTS_TRACE_PARAM) {
+  AttnArgs a;
+  a.q = q; a.kcache = kcache; a.vcache = vcache; a.out = out; a.cur_len = cur_len; a.valid_from = valid_from;
+  a.slot0 = slot0; a.heads = heads; a.smax = smax; a.D = D; a.nsplit = nsplit_;
+  TraceScope trace(5, IXTTS_TRACE_SEQ);
   using LY = KVLayout<KVT>;
   __shared__ float sm[NW][LY::LPP][2 + LY::DPL];
   const int hh = blockIdx.x, split = blockIdx.y, slot = a.slot0 + blockIdx.z;
@@ -632,6 +742,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
       hi = min(S_end, lo + chunk);
     }
   }, nsplit == 1);
+  trace.mid(st.l);
   float M, L, O;
   const float o = attn_merge<KVT, NW>(st, sm, wave, lane, &M, &L, &O);
   if (threadIdx.x < 64) {
@@ -647,6 +758,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(AttnArgs a) {
       pp[4 + threadIdx.x] = O;
     }
   }
+  trace.end();
 }
 
 // ------------------------------------------------------------------------------------
