@@ -25,6 +25,13 @@ struct LayerOff {
   size_t ln1_w, ln1_b, wqkv, bqkv, wo, bo, ln2_w, ln2_b, wfc, bfc, wpr, bpr;
 };
 
+// split-S decode attention: NSP workgroups per (head, slot); bucket k is instantiated for IT0 = ATTN_IT[k] key blocks per
+// workgroup and covers contexts up to ATTN_IT[k] * NSP * 32 keys (bf16 cache; the fp32 cache holds half as many keys per
+// wave-load and doubles IT0 instead)
+constexpr int ATTN_NSP = 4, NBKT = 4;
+constexpr int ATTN_IT[NBKT] = {4, 8, 12, 16};
+constexpr int attn_cover(int bkt) { return ATTN_IT[bkt] * ATTN_NSP * 32; }
+
 template <int D>
 struct Dims;
 template <>
@@ -56,7 +63,6 @@ struct ixtts_gpt {
   bool finalized = false;
   // state
   float *h = nullptr, *q = nullptr, *ff = nullptr, *att = nullptr, *part = nullptr, *logits = nullptr, *rowbuf = nullptr;
-  int nsplit[ixtts::MAXB + 1];  // split-S factor of the decode attention per batch size
   float* stage = nullptr;  // fp32 [N][K] staging of every matrix until finalize folds/converts it
   size_t stage_floats = 0;
   void *kc = nullptr, *vc = nullptr;
@@ -70,8 +76,11 @@ struct ixtts_gpt {
   float* scratch = nullptr;
   size_t scratch_floats = 0;
   hipStream_t cap_stream = nullptr;
-  hipGraphExec_t step_exec[ixtts::MAXB + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // 1 decode step
-  hipGraphExec_t multi_exec[ixtts::MAXB + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // STEPS_PER_GRAPH steps
+  // decode graphs per (batch, attention bucket): [.][NBKT] is the any-length legacy attention kernel
+  hipGraphExec_t step_exec[ixtts::MAXB + 1][ixtts::NBKT + 1] = {};   // 1 decode step
+  hipGraphExec_t multi_exec[ixtts::MAXB + 1][ixtts::NBKT + 1] = {};  // STEPS_PER_GRAPH steps
+  bool attn_split = true;  // IXTTS_ATTN=legacy turns the split-S kernel off (A/B timing, fallback test)
+  int attn_bucket = ixtts::NBKT;  // bucket the graph being captured is built for
   int host_prompt_len[ixtts::MAXB + 2];
   int host_gen_est[ixtts::MAXB + 2];
   // beam-sample state (gpt_beam.hip): beams occupy slots 0..num_beams-1
@@ -79,7 +88,7 @@ struct ixtts_gpt {
   float *beam_scores = nullptr, *hyp_score = nullptr, *hyp_worst = nullptr;
   int *beam_src = nullptr, *hyp_len = nullptr, *n_hyp = nullptr, *beam_done = nullptr, *beam_forced_flag = nullptr;
   int32_t *hyp_tok = nullptr, *beam_forced = nullptr;
-  hipGraphExec_t beam_exec = nullptr, beam_multi_exec = nullptr;
+  hipGraphExec_t beam_exec[ixtts::NBKT + 1] = {}, beam_multi_exec[ixtts::NBKT + 1] = {};
   int beam_exec_nb = 0;
   // batched-rows workspace (prefill / latent): [max_seq][D] x4 + [max_seq][4D]
   float *rx = nullptr, *rxn = nullptr, *rq = nullptr, *ratt = nullptr, *rff = nullptr;

@@ -89,12 +89,10 @@ static int gemv_out(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.slot0 = slot0;
   a.out = h->h;
   a.out_stride = D;
-  a.nsplit = h->nsplit[B];
-  if (a.nsplit > 1) {
+  if (h->attn_bucket < NBKT) {  // merge the split-S partials while staging
+    static_assert(ATTN_NSP == 4, "merge variant");
     a.xin = h->part;
-    if (a.nsplit == 2) return launch_gemv<WT, KVT, D, DM::R1, DM::U_OUT, B, IN_ATTN2, EPI_RESID>(a, st);
-    if (a.nsplit == 4) return launch_gemv<WT, KVT, D, DM::R1, DM::U_OUT, B, IN_ATTN4, EPI_RESID>(a, st);
-    return launch_gemv<WT, KVT, D, DM::R1, DM::U_OUT, B, IN_ATTN, EPI_RESID>(a, st);
+    return launch_gemv<WT, KVT, D, DM::R1, DM::U_OUT, B, IN_ATTN4, EPI_RESID, 4, true>(a, st);
   }
   a.xin = h->att;
   return launch_gemv<WT, KVT, D, DM::R1, DM::U_OUT, B, IN_PLAIN, EPI_RESID>(a, st);
@@ -147,7 +145,7 @@ static int gemv_head(ixtts_gpt* h, int slot0, float* norm_out, hipStream_t st) {
   a.out = h->logits;
   a.out_stride = h->V;
   a.norm_out = norm_out;
-  return launch_gemv<WT, KVT, D, DM::R1, DM::U_HEAD, B, IN_LN2, EPI_LOGITS>(a, st);
+  return launch_gemv<WT, KVT, D, DM::R1, DM::U_HEAD, B, IN_LN2, EPI_LOGITS, 4, true>(a, st);
 }
 
 template <typename WT, typename KVT, int D, int B>
@@ -155,24 +153,26 @@ static int forward_layers(ixtts_gpt* h, int slot0, hipStream_t st) {
   const size_t lstride = (size_t)h->slots * D * h->smax * sizeof(KVT);
   for (int l = 0; l < h->L; ++l) {
     IX_TRY((gemv_qkv<WT, KVT, D, B>(h, l, slot0, st)));
-    AttnArgs t;
-    t.q = h->q;
-    t.kcache = (uint8_t*)h->kc + l * lstride;
-    t.vcache = (uint8_t*)h->vc + l * lstride;
-    t.nsplit = h->nsplit[B];
-    t.out = t.nsplit > 1 ? h->part : h->att;
-    t.cur_len = h->cur_len;
-    t.valid_from = h->valid_from;
-    t.slot0 = slot0;
-    t.heads = h->H;
-    t.smax = h->smax;
-    t.D = D;
-    // measured r01 (B=2, bf16): 8 waves x 4 row-groups in flight is the best compromise between the
-    // speculative first pass at short context (5.4 us at S=160) and the stream at long context (12.6 us at S=1220)
-    if (t.nsplit > 1) hipLaunchKernelGGL((attn_decode_kernel<KVT, 4, 8>), dim3(h->H, t.nsplit, B), dim3(256), 0, st, t.q, t.kcache, t.vcache, t.cur_len,
-                                          t.valid_from, t.smax, t.heads, t.slot0, t.D, t.out, t.nsplit IXTTS_TRACE_ARG);
-    else hipLaunchKernelGGL((attn_decode_kernel<KVT, 8, 4>), dim3(h->H, 1, B), dim3(512), 0, st, t.q, t.kcache, t.vcache, t.cur_len, t.valid_from,
-                            t.smax, t.heads, t.slot0, t.D, t.out, t.nsplit IXTTS_TRACE_ARG);
+    const void* kcl = (uint8_t*)h->kc + l * lstride;
+    const void* vcl = (uint8_t*)h->vc + l * lstride;
+    if (h->attn_bucket < NBKT) {
+      constexpr int F = 8 / KVLayout<KVT>::PPW;  // fp32 cache: half the keys per wave-load, twice the blocks
+      const dim3 grid(h->H, ATTN_NSP, B);
+#define IX_ATTN_SPLIT(IT) \
+  hipLaunchKernelGGL((attn_split_kernel<KVT, IT * F, ATTN_NSP>), grid, dim3(256), 0, st, h->q, kcl, vcl, h->cur_len, h->valid_from, h->smax, h->H, slot0, D, \
+                     h->part IXTTS_TRACE_ARG)
+      switch (h->attn_bucket) {
+        case 0: IX_ATTN_SPLIT(ATTN_IT[0]); break;
+        case 1: IX_ATTN_SPLIT(ATTN_IT[1]); break;
+        case 2: IX_ATTN_SPLIT(ATTN_IT[2]); break;
+        default: IX_ATTN_SPLIT(ATTN_IT[3]); break;
+      }
+#undef IX_ATTN_SPLIT
+    } else {
+      // any context length: one workgroup per (head, slot), online softmax over as many passes as it takes
+      hipLaunchKernelGGL((attn_decode_kernel<KVT, 8, 4>), dim3(h->H, 1, B), dim3(512), 0, st, h->q, kcl, vcl, h->cur_len, h->valid_from, h->smax,
+                         h->H, slot0, D, h->att, 1 IXTTS_TRACE_ARG);
+    }
     IX_TRY((gemv_out<WT, KVT, D, B>(h, l, slot0, st)));
     IX_TRY((gemv_fc<WT, KVT, D, B>(h, l, slot0, st)));
     IX_TRY((gemv_pr<WT, KVT, D, B>(h, l, slot0, st)));
@@ -369,12 +369,7 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   hipMemset(h->seen, 0, (size_t)S * V);
   hipMemset(h->logits, 0, (size_t)S * V * 4);
   if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
-  // split-S factor of the decode attention (IXTTS_NSPLIT overrides, for A/B timing and the split-path test)
-  for (int b = 1; b <= MAXB; ++b) {
-    int ns = 1;  // measured r01: consumer-side merge costs more than the split saves at S <= 1300
-    if (const char* e = getenv("IXTTS_NSPLIT")) ns = std::max(1, std::min(NSPLIT_MAX, atoi(e)));
-    h->nsplit[b] = ns;
-  }
+  if (const char* e = getenv("IXTTS_ATTN")) h->attn_split = strcmp(e, "legacy") != 0;
   memset(h->host_prompt_len, 0, sizeof(h->host_prompt_len));
   memset(h->host_gen_est, 0, sizeof(h->host_gen_est));
   *out = h;
@@ -533,9 +528,10 @@ extern "C" int ixtts_gpt_prefill(ixtts_gpt* h, int b, const float* embeds, int n
 // ------------------------------------------------------------------------------------ decode
 // One graph = `reps` consecutive decode steps (sampler -> 24 layers -> head, 122 kernels each): replaying an
 // 8-step graph amortises the ~10-16 us host cost of a graph launch over 8 tokens.
-static int build_step_graph(ixtts_gpt* h, int B, int reps, hipGraphExec_t* out, bool beam = false) {
+static int build_step_graph(ixtts_gpt* h, int B, int reps, int bucket, hipGraphExec_t* out, bool beam = false) {
   hipGraph_t g;
   hipStream_t cs = h->cap_stream;
+  h->attn_bucket = bucket;
   IX_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
   int rc = IXTTS_OK;
   for (int r = 0; r < reps && rc == IXTTS_OK; ++r) {
@@ -550,6 +546,14 @@ static int build_step_graph(ixtts_gpt* h, int B, int reps, hipGraphExec_t* out, 
   IX_HIP(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
   IX_HIP(hipGraphDestroy(g));
   return IXTTS_OK;
+}
+
+// smallest attention bucket that holds `ctx` keys (NBKT: the any-length kernel)
+static int pick_bucket(const ixtts_gpt* h, int ctx) {
+  if (!h->attn_split) return NBKT;
+  for (int k = 0; k < NBKT; ++k)
+    if (ctx <= attn_cover(k)) return k;
+  return NBKT;
 }
 
 extern "C" int ixtts_gpt_decode(ixtts_gpt* h, int n_active, int n_steps, const ixtts_sampler_cfg* sc, void* stream) {
@@ -567,15 +571,18 @@ extern "C" int ixtts_gpt_decode(ixtts_gpt* h, int n_active, int n_steps, const i
     IX_ARG(h->host_prompt_len[b] + h->host_gen_est[b] + n_steps < h->smax, "gpt_decode: slot %d would overflow max_seq %d", b, h->smax);
   }
   hipStream_t st = (hipStream_t)stream;
-  if (!h->step_exec[n_active]) {
-    IX_TRY(build_step_graph(h, n_active, 1, &h->step_exec[n_active]));
-    IX_TRY(build_step_graph(h, n_active, STEPS_PER_GRAPH, &h->multi_exec[n_active]));
-  }
   h->samp_host = *sc;
   IX_HIP(hipMemcpyAsync(h->d_samp, &h->samp_host, sizeof(ixtts_sampler_cfg), hipMemcpyHostToDevice, st));
-  int left = n_steps;
-  for (; left >= STEPS_PER_GRAPH; left -= STEPS_PER_GRAPH) IX_HIP(hipGraphLaunch(h->multi_exec[n_active], st));
-  for (; left > 0; --left) IX_HIP(hipGraphLaunch(h->step_exec[n_active], st));
+  int ctx0 = 0;  // keys the longest sequence holds before this call (the host counts the steps it issues)
+  for (int b = 0; b < n_active; ++b) ctx0 = std::max(ctx0, h->host_prompt_len[b] + h->host_gen_est[b]);
+  for (int done = 0; done < n_steps;) {
+    const int reps = n_steps - done >= STEPS_PER_GRAPH ? STEPS_PER_GRAPH : 1;
+    const int bkt = pick_bucket(h, ctx0 + done + reps + 1);
+    hipGraphExec_t* slot = reps > 1 ? &h->multi_exec[n_active][bkt] : &h->step_exec[n_active][bkt];
+    if (!*slot) IX_TRY(build_step_graph(h, n_active, reps, bkt, slot));
+    IX_HIP(hipGraphLaunch(*slot, st));
+    done += reps;
+  }
   for (int b = 0; b < n_active; ++b) h->host_gen_est[b] += n_steps;
   return IXTTS_OK;
 }
@@ -638,19 +645,25 @@ extern "C" int ixtts_gpt_beam_decode(ixtts_gpt* h, int n_steps, const ixtts_samp
   const int nb = h->num_beams;
   IX_ARG(h->host_prompt_len[0] + h->host_gen_est[0] + n_steps < h->smax, "gpt_beam_decode: would overflow max_seq %d", h->smax);
   hipStream_t st = (hipStream_t)stream;
-  if (!h->beam_exec || h->beam_exec_nb != nb) {
-    if (h->beam_exec) hipGraphExecDestroy(h->beam_exec);
-    if (h->beam_multi_exec) hipGraphExecDestroy(h->beam_multi_exec);
-    h->beam_exec = h->beam_multi_exec = nullptr;
-    IX_TRY(build_step_graph(h, nb, 1, &h->beam_exec, true));
-    IX_TRY(build_step_graph(h, nb, STEPS_PER_GRAPH, &h->beam_multi_exec, true));
+  if (h->beam_exec_nb != nb) {
+    for (int k = 0; k <= NBKT; ++k) {
+      if (h->beam_exec[k]) hipGraphExecDestroy(h->beam_exec[k]);
+      if (h->beam_multi_exec[k]) hipGraphExecDestroy(h->beam_multi_exec[k]);
+      h->beam_exec[k] = h->beam_multi_exec[k] = nullptr;
+    }
     h->beam_exec_nb = nb;
   }
   h->samp_host = *sc;
   IX_HIP(hipMemcpyAsync(h->d_samp, &h->samp_host, sizeof(ixtts_sampler_cfg), hipMemcpyHostToDevice, st));
-  int left = n_steps;
-  for (; left >= STEPS_PER_GRAPH; left -= STEPS_PER_GRAPH) IX_HIP(hipGraphLaunch(h->beam_multi_exec, st));
-  for (; left > 0; --left) IX_HIP(hipGraphLaunch(h->beam_exec, st));
+  const int ctx0 = h->host_prompt_len[0] + h->host_gen_est[0];
+  for (int done = 0; done < n_steps;) {
+    const int reps = n_steps - done >= STEPS_PER_GRAPH ? STEPS_PER_GRAPH : 1;
+    const int bkt = pick_bucket(h, ctx0 + done + reps + 1);
+    hipGraphExec_t* slot = reps > 1 ? &h->beam_multi_exec[bkt] : &h->beam_exec[bkt];
+    if (!*slot) IX_TRY(build_step_graph(h, nb, reps, bkt, slot, true));
+    IX_HIP(hipGraphLaunch(*slot, st));
+    done += reps;
+  }
   for (int b = 0; b < nb; ++b) h->host_gen_est[b] += n_steps;
   return IXTTS_OK;
 }
@@ -813,12 +826,14 @@ extern "C" double ixtts_gpt_step_bytes(const ixtts_gpt* h, int B, int S) {
 
 extern "C" int ixtts_gpt_destroy(ixtts_gpt* h) {
   if (!h) return IXTTS_OK;
-  for (int b = 0; b <= MAXB; ++b) {
-    if (h->step_exec[b]) hipGraphExecDestroy(h->step_exec[b]);
-    if (h->multi_exec[b]) hipGraphExecDestroy(h->multi_exec[b]);
+  for (int k = 0; k <= NBKT; ++k) {
+    for (int b = 0; b <= MAXB; ++b) {
+      if (h->step_exec[b][k]) hipGraphExecDestroy(h->step_exec[b][k]);
+      if (h->multi_exec[b][k]) hipGraphExecDestroy(h->multi_exec[b][k]);
+    }
+    if (h->beam_exec[k]) hipGraphExecDestroy(h->beam_exec[k]);
+    if (h->beam_multi_exec[k]) hipGraphExecDestroy(h->beam_multi_exec[k]);
   }
-  if (h->beam_exec) hipGraphExecDestroy(h->beam_exec);
-  if (h->beam_multi_exec) hipGraphExecDestroy(h->beam_multi_exec);
   if (h->cap_stream) hipStreamDestroy(h->cap_stream);
   void* ptrs[] = {h->arena, h->stage, h->kc, h->vc, h->h, h->q, h->ff, h->att, h->part, h->logits, h->rowbuf, h->cur_len, h->gen_count,
                   h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->probs, h->scratch, h->beam_scores, h->hyp_score, h->hyp_worst, h->beam_src, h->hyp_len,

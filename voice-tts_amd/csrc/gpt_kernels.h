@@ -64,7 +64,7 @@ struct TraceScope {
 #define IXTTS_TRACE_SEQ 0
 #endif
 
-enum { IN_LN = 0, IN_LN2 = 1, IN_PLAIN = 2, IN_ATTN = 3, IN_ATTN2 = 4, IN_ATTN4 = 5 };  // IN_ATTNn: split-S merge, n compile-time
+enum { IN_LN = 0, IN_LN2 = 1, IN_PLAIN = 2, IN_ATTN2 = 4, IN_ATTN4 = 5 };  // IN_ATTNn: merge of n split-S attention partials
 
 // split-S attention partials: per (slot, head, split) [m, l, pad, pad, acc[64]] (acc 16-byte aligned)
 constexpr int PART_STRIDE = 4 + 64;
@@ -159,9 +159,52 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int lane, int u
 
 // ------------------------------------------------------------------------------------
 // Register-resident GEMV (K = model_dim kernels: QKV, out-proj, FC, head).
-// XLDS: the activation rows reach the waves through LDS (one global read per workgroup) instead of every wave
-// reading its ROWS copies from L2 -- with 5 waves x 2 rows that private traffic through the CU's L1 was twice the
-// weight stream itself (r01 timeline: activations ready 3.1 us after entry, weights reduced at 4.3 us).
+//
+// Timeline of one workgroup (r01 traces, tools/trace_decode.py): every global load is issued in the first ~0.2 us in
+// the order activations -> epilogue operands -> weights (vmcnt retires in order, so each consumer waits only for what
+// it needs), pinned with sched_barrier(0): left alone the scheduler sinks the small loads to their use at the end of the
+// kernel (one more memory round trip) or batches the activation loads; and no load sits under a branch (a predicated load
+// rejoins with a conservative "wait for everything").  The activations land after ~1.4 us, the weights stream in behind
+// them, so what remains on the critical path is ALU work at one wave per SIMD (4 cycles per wave64 instruction):
+//   * XLDS: the workgroup reads the activation rows once (not ROWS copies per wave through the CU's L1), does the
+//     LayerNorm statistics once with two block reductions, and hands the normalised rows to the waves through LDS;
+//     IN_ATTN2/4 merge the split-S attention partials in the same staging step;
+//   * the dot products run on packed fp32 math (v_pk_fma_f32: two FMAs per lane per instruction).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename WT>
+__device__ __forceinline__ void unpack2(const uint4& r, f32x2 (&w)[WVec<WT>::VEC / 2]);
+template <>
+__device__ __forceinline__ void unpack2<float>(const uint4& r, f32x2 (&w)[2]) {
+  w[0] = f32x2{__uint_as_float(r.x), __uint_as_float(r.y)};
+  w[1] = f32x2{__uint_as_float(r.z), __uint_as_float(r.w)};
+}
+template <>
+__device__ __forceinline__ void unpack2<bf16>(const uint4& r, f32x2 (&w)[4]) {
+  w[0] = f32x2{lo_bf16(r.x), hi_bf16(r.x)};
+  w[1] = f32x2{lo_bf16(r.y), hi_bf16(r.y)};
+  w[2] = f32x2{lo_bf16(r.z), hi_bf16(r.z)};
+  w[3] = f32x2{lo_bf16(r.w), hi_bf16(r.w)};
+}
+
+// sums of s[0..B) over the workgroup's WPB waves, in a fixed order (bit-reproducible); `red` is a private [WPB][B] LDS region
+template <int B, int WPB>
+__device__ __forceinline__ void block_sum(float (&s)[B], float* red, int wave, int lane) {
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const float t = wave_sum63(s[b]);
+    if (lane == 63) red[wave * B + b] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) t += red[w * B + b];
+    s[b] = t;
+  }
+}
+
 template <typename WT, int K, int ROWS, int UNITS, int B, int INP, int EPI, typename KVT, int WPB = 4, bool XLDS = false>
 __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, const float* xin, const float* bias, float* out, int N, int slot0, int out_stride, int smax,
                                                         void* kcache, void* vcache, const int* cur_len, int heads, int nsplit,
@@ -177,89 +220,46 @@ __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, cons
   constexpr int PER = 64 * VEC;       // elements per wave-load
   constexpr int NL = ROWS * K / PER;  // loads per lane per unit
   static_assert(ROWS * K % PER == 0, "unit must be a whole number of wave loads");
-  static_assert(K % VEC == 0, "row length must be a multiple of the vector width");
+  static_assert(K % VEC == 0 && K % 4 == 0, "row length must be a multiple of the vector width");
+  static_assert(XLDS || INP == IN_PLAIN, "LayerNorm / split-S merge inputs are staged by the workgroup (XLDS)");
+  constexpr int NSP = INP == IN_ATTN2 ? 2 : (INP == IN_ATTN4 ? 4 : 1);
+  constexpr int NPASS = INP == IN_LN ? 1 : (INP == IN_LN2 ? 2 : 0);
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int unit0 = (blockIdx.x * WPB + wave) * UNITS;  // WPB waves per workgroup: chosen so the grid is one WG per CU
   const int n_units = (a.N + ROWS - 1) / ROWS;
-  if (!XLDS && unit0 >= n_units) return;  // wave-uniform; the non-XLDS kernel has no barriers
+  if (!XLDS && unit0 >= n_units) return;  // wave-uniform; only the XLDS kernels have barriers
 
-  // ---- 1. activation slice -> registers (L2-resident, issued first: vmcnt retires in order)
-  float xr[B][NL][VEC];
-  constexpr int X4 = B * K / 4, NT = 64 * WPB, XV = (X4 + NT - 1) / NT;  // XLDS: float4 per thread
-  float4 xstage[XLDS ? XV : 1];
-  if constexpr (XLDS) {
-    static_assert(INP == IN_LN || INP == IN_LN2 || INP == IN_PLAIN, "XLDS stages plain activation rows");
+  // ---- 1. activations: issue the loads
+  constexpr int K4 = K / 4, X4 = B * K4, NT = 64 * WPB, XV = (X4 + NT - 1) / NT;  // XLDS: float4 per thread
+  f32x2 xr[B][NL][VEC / 2];
+  float4 xs4[XLDS ? XV : 1];             // staged element i of this thread: float4 number threadIdx.x + i*NT of [B][K]
+  float4 lw4[NPASS == 2 ? XV : 1], lb4[NPASS == 2 ? XV : 1];
+  float2 pml[NSP > 1 ? XV : 1][NSP];     // split-S partials: (m, l) and the accumulator slice
+  float4 pac[NSP > 1 ? XV : 1][NSP];
+  if constexpr (XLDS && NSP == 1) {
     const float* xbase = a.xin + (size_t)a.slot0 * K;  // slots are contiguous rows
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
-      const int idx = threadIdx.x + i * NT;
-      xstage[i] = (X4 % NT == 0 || idx < X4) ? *reinterpret_cast<const float4*>(xbase + (size_t)idx * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int idx = min((int)threadIdx.x + i * NT, X4 - 1);
+      xs4[i] = *reinterpret_cast<const float4*>(xbase + (size_t)idx * 4);
+      if constexpr (NPASS == 2) {  // explicit affine of the first norm (ln_f); the last norm's affine is folded into W
+        lw4[i] = *reinterpret_cast<const float4*>(a.ln_w + (idx % K4) * 4);
+        lb4[i] = *reinterpret_cast<const float4*>(a.ln_b + (idx % K4) * 4);
+      }
     }
-  } else if constexpr (INP == IN_ATTN || INP == IN_ATTN2 || INP == IN_ATTN4) {
-    constexpr int NSP = INP == IN_ATTN2 ? 2 : (INP == IN_ATTN4 ? 4 : 0);  // 0: runtime a.nsplit
-    const int nsp = NSP ? NSP : a.nsplit;
-    // flash-decode merge of the split-S partials, straight into the lane's slice:
-    // x[k] = sum_s acc_s[k] e^{m_s - M} / sum_s l_s e^{m_s - M}
+  } else if constexpr (XLDS) {
     constexpr int H = K / HD;
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
+    for (int i = 0; i < XV; ++i) {
+      const int idx = min((int)threadIdx.x + i * NT, X4 - 1);
+      const int b = idx / K4, k0 = (idx % K4) * 4;
+      const float* p = a.xin + ((size_t)((a.slot0 + b) * H + k0 / HD) * NSP) * PART_STRIDE;
 #pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        const int k0 = (j * PER + lane * VEC) % K;
-        const int hh = k0 / HD, d0 = k0 % HD;
-        const float* p = a.xin + ((size_t)((a.slot0 + b) * H + hh) * nsp) * PART_STRIDE;
-        float L = 0.f, o[VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) o[v] = 0.f;
-        if constexpr (NSP > 0) {
-          // all loads first (compile-time split count), then the merge
-          float2 ml[NSP];
-          float4 av[NSP][VEC / 4];
-#pragma unroll
-          for (int sidx = 0; sidx < NSP; ++sidx) {
-            const float* ps = p + sidx * PART_STRIDE;
-            ml[sidx] = *reinterpret_cast<const float2*>(ps);
-#pragma unroll
-            for (int v4 = 0; v4 < VEC / 4; ++v4) av[sidx][v4] = *reinterpret_cast<const float4*>(ps + 4 + d0 + v4 * 4);
-          }
-          float M = -INFINITY;
-#pragma unroll
-          for (int sidx = 0; sidx < NSP; ++sidx) M = fmaxf(M, ml[sidx].x);
-#pragma unroll
-          for (int sidx = 0; sidx < NSP; ++sidx) {
-            const float w = (ml[sidx].x > -INFINITY) ? expf(ml[sidx].x - M) : 0.f;
-            L = fmaf(ml[sidx].y, w, L);
-#pragma unroll
-            for (int v4 = 0; v4 < VEC / 4; ++v4) {
-              o[v4 * 4 + 0] = fmaf(av[sidx][v4].x, w, o[v4 * 4 + 0]);
-              o[v4 * 4 + 1] = fmaf(av[sidx][v4].y, w, o[v4 * 4 + 1]);
-              o[v4 * 4 + 2] = fmaf(av[sidx][v4].z, w, o[v4 * 4 + 2]);
-              o[v4 * 4 + 3] = fmaf(av[sidx][v4].w, w, o[v4 * 4 + 3]);
-            }
-          }
-        } else {
-          float M = -INFINITY;
-          for (int sidx = 0; sidx < nsp; ++sidx) M = fmaxf(M, p[sidx * PART_STRIDE]);
-          for (int sidx = 0; sidx < nsp; ++sidx) {
-            const float* ps = p + sidx * PART_STRIDE;
-            const float2 ml = *reinterpret_cast<const float2*>(ps);
-            const float w = (ml.x > -INFINITY) ? expf(ml.x - M) : 0.f;
-            L = fmaf(ml.y, w, L);
-#pragma unroll
-            for (int v4 = 0; v4 < VEC / 4; ++v4) {
-              const float4 t = *reinterpret_cast<const float4*>(ps + 4 + d0 + v4 * 4);
-              o[v4 * 4 + 0] = fmaf(t.x, w, o[v4 * 4 + 0]);
-              o[v4 * 4 + 1] = fmaf(t.y, w, o[v4 * 4 + 1]);
-              o[v4 * 4 + 2] = fmaf(t.z, w, o[v4 * 4 + 2]);
-              o[v4 * 4 + 3] = fmaf(t.w, w, o[v4 * 4 + 3]);
-            }
-          }
-        }
-        const float inv = 1.0f / L;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) xr[b][j][v] = o[v] * inv;
+      for (int sp = 0; sp < NSP; ++sp) {
+        pml[i][sp] = *reinterpret_cast<const float2*>(p + sp * PART_STRIDE);
+        pac[i][sp] = *reinterpret_cast<const float4*>(p + sp * PART_STRIDE + 4 + k0 % HD);
       }
     }
   } else {
@@ -268,22 +268,18 @@ __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, cons
       const float* xs = a.xin + (size_t)(a.slot0 + b) * K;
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
-        const int e = j * PER + lane * VEC;
-        const int k0 = e % K;
+        const int k0 = (j * PER + lane * VEC) % K;
 #pragma unroll
         for (int v4 = 0; v4 < VEC / 4; ++v4) {
           const float4 t = *reinterpret_cast<const float4*>(xs + k0 + v4 * 4);
-          xr[b][j][v4 * 4 + 0] = t.x; xr[b][j][v4 * 4 + 1] = t.y; xr[b][j][v4 * 4 + 2] = t.z; xr[b][j][v4 * 4 + 3] = t.w;
+          xr[b][j][v4 * 2] = f32x2{t.x, t.y};
+          xr[b][j][v4 * 2 + 1] = f32x2{t.z, t.w};
         }
       }
     }
   }
-  // sched_barrier(0): nothing crosses.  The issue order activations -> epilogue operands -> weights is the design
-  // (vmcnt retires in order, so the first consumer waits only for what it needs); left alone, the scheduler sinks the
-  // small loads to their use at the end of the kernel (a whole extra memory round trip) or batches the activation loads.
   __builtin_amdgcn_sched_barrier(0);
-  // ---- 2. epilogue operands of the rows this lane will write
-  // (every lane loads, indices clamped: a load under a branch forces a full vmcnt wait where the branch rejoins)
+  // ---- 2. epilogue operands of the rows this lane will write (every lane loads, indices clamped)
   float pre_bias[UNITS], pre_res[UNITS];
   int pre_pos = 0;
   const int elane = min(lane, ROWS * B - 1);
@@ -296,15 +292,11 @@ __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, cons
   }
   if constexpr (EPI == EPI_QKV) pre_pos = a.cur_len[a.slot0 + elane % B];
   __builtin_amdgcn_sched_barrier(0);
-  // ---- 3. weight stream (HBM)
+  // ---- 3. weight stream (HBM): unconditional, addresses clamped; products of clamped elements are dropped in step 5
   uint4 wraw[UNITS][NL];
 #pragma unroll
   for (int u = 0; u < UNITS; ++u) {
-    // unconditional loads (addresses clamped, products of clamped elements dropped in step 5): a predicated load becomes a branch, and across
-    // branches the compiler's vmcnt bookkeeping degrades to "wait for everything" -- the activations, issued first,
-    // would then only be usable once the whole weight stream has landed (r01 timeline: 3.1 us instead of 1.5 us)
-    const int unit = unit0 + u;
-    const int unit_c = min(unit, n_units - 1);
+    const int unit_c = min(unit0 + u, n_units - 1);
     const WT* base = reinterpret_cast<const WT*>(a.wt) + (size_t)unit_c * ROWS * K;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
@@ -313,12 +305,83 @@ __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, cons
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  // ---- 4. workgroup staging: split-S merge | LayerNorm (gain/bias of the norm feeding the matrix are pre-folded) -> LDS
   if constexpr (XLDS) {
     __shared__ __attribute__((aligned(16))) float xsh[B * K];
+    __shared__ float red[(NPASS > 0 ? 2 * NPASS : 1) * WPB * B];
+    if constexpr (NSP > 1) {
+      // flash-decode merge: x = sum_s acc_s e^{m_s - M} / sum_s l_s e^{m_s - M}
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        float M = -INFINITY;
+#pragma unroll
+        for (int sp = 0; sp < NSP; ++sp) M = fmaxf(M, pml[i][sp].x);
+        float L = 0.f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int sp = 0; sp < NSP; ++sp) {
+          const float w = (pml[i][sp].x > -INFINITY) ? expf(pml[i][sp].x - M) : 0.f;  // an empty split has m = -inf, l = 0
+          L = fmaf(pml[i][sp].y, w, L);
+          o.x = fmaf(pac[i][sp].x, w, o.x); o.y = fmaf(pac[i][sp].y, w, o.y);
+          o.z = fmaf(pac[i][sp].z, w, o.z); o.w = fmaf(pac[i][sp].w, w, o.w);
+        }
+        const float inv = 1.0f / L;
+        xs4[i] = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+      }
+    }
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      // element i of this thread belongs to slot (threadIdx.x + i*NT) / K4; elements past the end count for no slot
+      float s[B], q[B];
+#pragma unroll
+      for (int b = 0; b < B; ++b) s[b] = 0.f;
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        const int idx = threadIdx.x + i * NT;
+        const int sl = (X4 % NT == 0 || idx < X4) ? idx / K4 : B;
+        const float v = (xs4[i].x + xs4[i].y) + (xs4[i].z + xs4[i].w);
+#pragma unroll
+        for (int b = 0; b < B; ++b) s[b] += (sl == b) ? v : 0.f;
+      }
+      block_sum<B, WPB>(s, red + (2 * pass) * WPB * B, wave, lane);
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        s[b] *= (1.0f / K);  // mean
+        q[b] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        const int idx = threadIdx.x + i * NT;
+        const int sl = (X4 % NT == 0 || idx < X4) ? idx / K4 : B;
+        float mean = 0.f;
+#pragma unroll
+        for (int b = 0; b < B; ++b) mean = (sl == b) ? s[b] : mean;
+        xs4[i].x -= mean; xs4[i].y -= mean; xs4[i].z -= mean; xs4[i].w -= mean;
+        const float v = fmaf(xs4[i].x, xs4[i].x, xs4[i].y * xs4[i].y) + fmaf(xs4[i].z, xs4[i].z, xs4[i].w * xs4[i].w);
+#pragma unroll
+        for (int b = 0; b < B; ++b) q[b] += (sl == b) ? v : 0.f;
+      }
+      block_sum<B, WPB>(q, red + (2 * pass + 1) * WPB * B, wave, lane);
+#pragma unroll
+      for (int b = 0; b < B; ++b) q[b] = 1.0f / sqrtf(q[b] * (1.0f / K) + 1e-5f);  // rstd
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        const int idx = threadIdx.x + i * NT;
+        const int sl = (X4 % NT == 0 || idx < X4) ? idx / K4 : B;
+        float rstd = 0.f;
+#pragma unroll
+        for (int b = 0; b < B; ++b) rstd = (sl == b) ? q[b] : rstd;
+        xs4[i].x *= rstd; xs4[i].y *= rstd; xs4[i].z *= rstd; xs4[i].w *= rstd;
+        if (NPASS == 2 && pass == 0) {
+          xs4[i].x = fmaf(xs4[i].x, lw4[i].x, lb4[i].x); xs4[i].y = fmaf(xs4[i].y, lw4[i].y, lb4[i].y);
+          xs4[i].z = fmaf(xs4[i].z, lw4[i].z, lb4[i].z); xs4[i].w = fmaf(xs4[i].w, lw4[i].w, lb4[i].w);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
       const int idx = threadIdx.x + i * NT;
-      if (X4 % NT == 0 || idx < X4) *reinterpret_cast<float4*>(xsh + idx * 4) = xstage[i];
+      if (X4 % NT == 0 || idx < X4) *reinterpret_cast<float4*>(xsh + idx * 4) = xs4[i];
     }
     __syncthreads();
 #pragma unroll
@@ -329,76 +392,35 @@ __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, cons
 #pragma unroll
         for (int v4 = 0; v4 < VEC / 4; ++v4) {
           const float4 t = *reinterpret_cast<const float4*>(xsh + b * K + k0 + v4 * 4);
-          xr[b][j][v4 * 4 + 0] = t.x; xr[b][j][v4 * 4 + 1] = t.y; xr[b][j][v4 * 4 + 2] = t.z; xr[b][j][v4 * 4 + 3] = t.w;
+          xr[b][j][v4 * 2] = f32x2{t.x, t.y};
+          xr[b][j][v4 * 2 + 1] = f32x2{t.z, t.w};
         }
       }
   }
-  // ---- 4. LayerNorm in registers (gain/bias of the norm feeding the matrix are pre-folded)
-  if constexpr (INP == IN_LN || INP == IN_LN2) {
-    constexpr int NPASS = (INP == IN_LN2) ? 2 : 1;
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-#pragma unroll
-      for (int b = 0; b < B; ++b) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < NL; ++j)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) s += xr[b][j][v];
-        const float mean = wave_sum(s) * (1.0f / (ROWS * K));
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < NL; ++j)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            const float d = xr[b][j][v] - mean;
-            q = fmaf(d, d, q);
-          }
-        const float var = wave_sum(q) * (1.0f / (ROWS * K));
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
-#pragma unroll
-        for (int j = 0; j < NL; ++j)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) xr[b][j][v] = (xr[b][j][v] - mean) * rstd;
-      }
-      if (INP == IN_LN2 && pass == 0) {
-        // explicit affine of the first norm (ln_f); the second norm's affine is folded
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-          const int k0 = (j * PER + lane * VEC) % K;
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            const float g = a.ln_w[k0 + v], bb = a.ln_b[k0 + v];
-#pragma unroll
-            for (int b = 0; b < B; ++b) xr[b][j][v] = fmaf(xr[b][j][v], g, bb);
-          }
-        }
-      }
-    }
-  }
-  trace.inputs(xr[0][0][0]);
-  // ---- 5. dot products, DPP reduction, epilogue
+  trace.inputs(xr[0][0][0].x);
+  // ---- 5. dot products (packed fp32), DPP reduction, epilogue
 #pragma unroll
   for (int u = 0; u < UNITS; ++u) {
     const int unit = unit0 + u;
     if (unit >= n_units) break;
+    const int rows_here = min(ROWS, a.N - unit * ROWS);
     float acc[ROWS][B];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r)
 #pragma unroll
       for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
-    const int rows_here = min(ROWS, a.N - unit * ROWS);
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int e = j * PER + lane * VEC;
       const int row = (e < rows_here * K) ? e / K : ROWS;  // ROWS: element beyond the matrix (its load was clamped)
-      float wv[VEC];
-      WVec<WT>::unpack(wraw[u][j], wv);
+      f32x2 w2[VEC / 2];
+      unpack2<WT>(wraw[u][j], w2);
 #pragma unroll
       for (int b = 0; b < B; ++b) {
-        float d = 0.f;
+        f32x2 d2 = w2[0] * xr[b][j][0];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) d = fmaf(wv[v], xr[b][j][v], d);
+        for (int v = 1; v < VEC / 2; ++v) d2 = __builtin_elementwise_fma(w2[v], xr[b][j][v], d2);
+        const float d = d2.x + d2.y;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) acc[r][b] += (row == r) ? d : 0.f;
       }
@@ -708,55 +730,148 @@ __device__ __forceinline__ void load_q_slice(const float* qp, int dp, float (&qv
   }
 }
 
+// Any-length fallback (contexts beyond the largest split-S bucket, IXTTS_ATTN=legacy): one workgroup per (head, slot).
 template <typename KVT, int NW, int IT>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* q, const void* kcache, const void* vcache,
                                                              const int* cur_len, const int* valid_from, int smax, int heads, int slot0,
                                                              int D, float* out, int nsplit_ IXTTS_TRACE_PARAM) {
-  AttnArgs a;
-  a.q = q; a.kcache = kcache; a.vcache = vcache; a.out = out; a.cur_len = cur_len; a.valid_from = valid_from;
-  a.slot0 = slot0; a.heads = heads; a.smax = smax; a.D = D; a.nsplit = nsplit_;
-  TraceScope trace(5, IXTTS_TRACE_SEQ);
   using LY = KVLayout<KVT>;
   __shared__ float sm[NW][LY::LPP][2 + LY::DPL];
-  const int hh = blockIdx.x, split = blockIdx.y, slot = a.slot0 + blockIdx.z;
+  TraceScope trace(5, IXTTS_TRACE_SEQ);
+  const int hh = blockIdx.x, slot = slot0 + blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dp = lane % LY::LPP;
   // scalar state first (its latency overlaps the first K/V pass), then q, then the K/V stream
-  const int cur = a.cur_len[slot];
-  const int vf = a.valid_from[slot];
+  const int cur = cur_len[slot];
+  const int vf = valid_from[slot];
   float qv[LY::DPL];
-  load_q_slice<KVT>(a.q + (size_t)slot * a.D + hh * HD, dp, qv);
-  const KVT* kb = reinterpret_cast<const KVT*>(a.kcache) + ((size_t)slot * a.heads + hh) * a.smax * HD + dp * LY::DPL;
-  const KVT* vb = reinterpret_cast<const KVT*>(a.vcache) + ((size_t)slot * a.heads + hh) * a.smax * HD + dp * LY::DPL;
+  load_q_slice<KVT>(q + (size_t)slot * D + hh * HD, dp, qv);
+  const KVT* kb = reinterpret_cast<const KVT*>(kcache) + ((size_t)slot * heads + hh) * smax * HD + dp * LY::DPL;
+  const KVT* vb = reinterpret_cast<const KVT*>(vcache) + ((size_t)slot * heads + hh) * smax * HD + dp * LY::DPL;
   SoftAcc<LY::DPL> st;
   st.init();
-  const int nsplit = a.nsplit;
-  attn_sweep<KVT, NW, IT>(st, kb, vb, qv, a.smax, wave, lane, [&](int& lo, int& hi) {
-    const int S_end = cur + 1;
-    if (nsplit == 1) {
-      lo = vf;
-      hi = S_end;
-    } else {  // an equal share of [valid_from, cur_len], rounded to 16-key groups
-      const int chunk = (((S_end - vf + nsplit - 1) / nsplit) + 15) & ~15;
-      lo = vf + split * chunk;
-      hi = min(S_end, lo + chunk);
-    }
-  }, nsplit == 1);
+  attn_sweep<KVT, NW, IT>(st, kb, vb, qv, smax, wave, lane, [&](int& lo, int& hi) {
+    lo = vf;
+    hi = cur + 1;
+  });
   trace.mid(st.l);
-  float M, L, O;
-  const float o = attn_merge<KVT, NW>(st, sm, wave, lane, &M, &L, &O);
-  if (threadIdx.x < 64) {
-    if (nsplit == 1) {
-      a.out[(size_t)slot * a.D + hh * HD + threadIdx.x] = o;
-    } else {
-      // an empty range leaves M = -inf, L = 0, O = 0: the consumer gives it weight 0
-      float* pp = a.out + (((size_t)slot * a.heads + hh) * nsplit + split) * PART_STRIDE;
-      if (threadIdx.x == 0) {
-        pp[0] = M;
-        pp[1] = L;
-      }
-      pp[4 + threadIdx.x] = O;
-    }
+  const float o = attn_merge<KVT, NW>(st, sm, wave, lane);
+  if (threadIdx.x < 64) out[(size_t)slot * D + hh * HD + threadIdx.x] = o;
+  trace.end();
+}
+
+// ------------------------------------------------------------------------------------
+// Split-S single-query attention, the default decode path: grid (H, NSP, B), 4 waves.  Workgroup `sp` of a (head, slot)
+// owns the 4*PPW-key blocks sp, sp + NSP, sp + 2 NSP, ... (interleaved, so the split is balanced at every context length
+// without knowing it), IT0 of them -- the host picks the instantiation whose coverage IT0 * NSP * 4 * PPW holds the
+// longest context of the graph it is about to launch (it counts the steps it has issued), so there is no loop:
+//   * every K and V load of the workgroup is issued at entry, before cur_len / valid_from have even arrived
+//     (addresses clamped to the cache, rows outside [valid_from, cur_len] masked afterwards); one memory round trip;
+//   * softmax in two phases over registers (all scores -> workgroup max through LDS -> weights), so no running
+//     rescale and no exp in the cross-lane / cross-wave merges: those are plain sums through LDS;
+//   * the 8- or 16-lane dot-product reduction runs on DPP (quad_perm / row_half_mirror / row_mirror), not the LDS crossbar.
+// Output: the un-normalised partial (m, l, acc[64]) of the split; the out-proj GEMV merges the NSP partials while it
+// stages its activations (IN_ATTN2 / IN_ATTN4).  r01 timeline at context 700, B=2: 8.1 us for the 40-workgroup
+// online-softmax kernel above (5.5 us of serial passes + 2.1 us of merge tail) -> see DESIGN.md for this one.
+template <int LPP>
+__device__ __forceinline__ float group_sum(float v) {  // sum over the LPP consecutive lanes of a key; every lane gets it
+  v += dpp_take<0xB1, 0xf, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_take<0x4E, 0xf, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_take<0x141, 0xf, 0xf>(v);  // row_half_mirror: the other quad of the 8
+  if constexpr (LPP == 16) v += dpp_take<0x140, 0xf, 0xf>(v);  // row_mirror: the other 8 of the 16
+  return v;
+}
+
+template <typename KVT, int IT0, int NSP>
+__global__ __launch_bounds__(256) void attn_split_kernel(const float* q, const void* kcache, const void* vcache, const int* cur_len,
+                                                         const int* valid_from, int smax, int heads, int slot0, int D, float* part IXTTS_TRACE_PARAM) {
+  using LY = KVLayout<KVT>;
+  constexpr int DPL = LY::DPL, LPP = LY::LPP, PPW = LY::PPW;
+  static_assert(LPP == 8 || LPP == 16, "lane group of a key");
+  __shared__ float wmax[4];
+  __shared__ __attribute__((aligned(16))) float racc[4][PPW][HD];
+  __shared__ float rl[4][PPW];
+  TraceScope trace(5, IXTTS_TRACE_SEQ);
+  const int hh = blockIdx.x, sp = blockIdx.y, slot = slot0 + blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pg = lane / LPP, dp = lane % LPP;
+  // ---- every load of the kernel, in the order it is consumed
+  const int cur = cur_len[slot];
+  const int vf = valid_from[slot];
+  float qv[DPL];
+  load_q_slice<KVT>(q + (size_t)slot * D + hh * HD, dp, qv);
+  const KVT* kb = reinterpret_cast<const KVT*>(kcache) + ((size_t)slot * heads + hh) * smax * HD + dp * DPL;
+  const KVT* vb = reinterpret_cast<const KVT*>(vcache) + ((size_t)slot * heads + hh) * smax * HD + dp * DPL;
+  uint4 kr[IT0], vr[IT0];
+#pragma unroll
+  for (int it = 0; it < IT0; ++it) {
+    const int p = ((it * NSP + sp) * 4 + wave) * PPW + pg;
+    kr[it] = *reinterpret_cast<const uint4*>(kb + (size_t)min(p, smax - 1) * HD);
+  }
+#pragma unroll
+  for (int it = 0; it < IT0; ++it) {
+    const int p = ((it * NSP + sp) * 4 + wave) * PPW + pg;
+    vr[it] = *reinterpret_cast<const uint4*>(vb + (size_t)min(p, smax - 1) * HD);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- scores of this lane group's IT0 keys
+  float s[IT0];
+  float lmax = -INFINITY;
+#pragma unroll
+  for (int it = 0; it < IT0; ++it) {
+    const int p = ((it * NSP + sp) * 4 + wave) * PPW + pg;
+    float kv[DPL];
+    kv_unpack(kr[it], kv);
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) d = fmaf(qv[i], kv[i], d);
+    d = group_sum<LPP>(d);
+    s[it] = (p >= vf && p <= cur) ? d : -INFINITY;
+    lmax = fmaxf(lmax, s[it]);
+  }
+#pragma unroll
+  for (int o = LPP; o <= 32; o <<= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+  if (lane == 0) wmax[wave] = lmax;
+  __syncthreads();
+  const float M = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  // ---- weights and the weighted sum of this lane's DPL dims over its keys
+  float l = 0.f, acc[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int it = 0; it < IT0; ++it) {
+    const bool ok = s[it] > -INFINITY;
+    const float pw = ok ? expf(s[it] - M) : 0.f;
+    float vv[DPL];
+    kv_unpack(vr[it], vv);
+    l += pw;
+    // rows outside the range were read speculatively and may hold anything (NaN/Inf bit patterns): 0 * NaN != 0
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) acc[i] = fmaf(pw, ok ? vv[i] : 0.f, acc[i]);
+  }
+  trace.mid(l);
+  // ---- plain sums over the PPW key groups of each wave and the 4 waves, through LDS in a fixed order
+#pragma unroll
+  for (int i = 0; i < DPL / 4; ++i)
+    *reinterpret_cast<float4*>(&racc[wave][pg][dp * DPL + 4 * i]) = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+  if (dp == 0) rl[wave][pg] = l;
+  __syncthreads();
+  float* pp = part + (((size_t)slot * heads + hh) * NSP + sp) * PART_STRIDE;
+  if (threadIdx.x < HD) {
+    float o = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int g = 0; g < PPW; ++g) o += racc[w][g][threadIdx.x];
+    pp[4 + threadIdx.x] = o;
+  } else if (threadIdx.x == HD) {
+    float L = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int g = 0; g < PPW; ++g) L += rl[w][g];
+    pp[0] = M;  // an empty split leaves M = -inf, L = 0, acc = 0: the consumer gives it weight 0
+    pp[1] = L;
   }
   trace.end();
 }
