@@ -28,8 +28,8 @@ struct LayerOff {
 // split-S decode attention: NSP workgroups per (head, slot); bucket k is instantiated for IT0 = ATTN_IT[k] key blocks per
 // workgroup and covers contexts up to ATTN_IT[k] * NSP * 32 keys (bf16 cache; the fp32 cache holds half as many keys per
 // wave-load and doubles IT0 instead)
-constexpr int ATTN_NSP = 4, NBKT = 4;
-constexpr int ATTN_IT[NBKT] = {4, 8, 12, 16};
+constexpr int ATTN_NSP = 4, NBKT = 8;
+constexpr int ATTN_IT[NBKT] = {2, 4, 6, 8, 10, 12, 14, 16};
 constexpr int attn_cover(int bkt) { return ATTN_IT[bkt] * ATTN_NSP * 32; }
 
 template <int D>

@@ -90,7 +90,7 @@ static int gemv_out(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.out = h->h;
   a.out_stride = D;
   if (h->attn_bucket < NBKT) {  // merge the split-S partials while staging
-    static_assert(ATTN_NSP == 4, "merge variant");
+    static_assert(ATTN_NSP == 4 && NBKT == 8, "merge variant / bucket switch above");
     a.xin = h->part;
     return launch_gemv<WT, KVT, D, DM::R1, DM::U_OUT, B, IN_ATTN4, EPI_RESID, 4, true>(a, st);
   }
@@ -165,7 +165,11 @@ static int forward_layers(ixtts_gpt* h, int slot0, hipStream_t st) {
         case 0: IX_ATTN_SPLIT(ATTN_IT[0]); break;
         case 1: IX_ATTN_SPLIT(ATTN_IT[1]); break;
         case 2: IX_ATTN_SPLIT(ATTN_IT[2]); break;
-        default: IX_ATTN_SPLIT(ATTN_IT[3]); break;
+        case 3: IX_ATTN_SPLIT(ATTN_IT[3]); break;
+        case 4: IX_ATTN_SPLIT(ATTN_IT[4]); break;
+        case 5: IX_ATTN_SPLIT(ATTN_IT[5]); break;
+        case 6: IX_ATTN_SPLIT(ATTN_IT[6]); break;
+        default: IX_ATTN_SPLIT(ATTN_IT[7]); break;
       }
 #undef IX_ATTN_SPLIT
     } else {
