@@ -61,6 +61,27 @@ int ixtts_attn_full_f32(const float* q_dev, const float* k_dev, const float* v_d
                         int head_dim, long stride_b, long stride_t, long stride_h, long ostride_b, long ostride_t,
                         long ostride_h, float scale, void* stream);
 
+/* Row N1 helpers -- the element/row chains between the DiT's GEMMs, one fp32 pass each (csrc/dit_ops.hip).
+ *
+ * ixtts_adaln_rmsnorm_f32  replaces AdaptiveLayerNorm.forward over RMSNorm (gpt_fast/model.py:18-37,362-372):
+ *     out[b,t,:] = wb[b,H:2H] + wb[b,0:H] * (x[b,t,:] * rsqrt(mean(x^2) + eps) * g), wb = project_layer(c) [B,2H].
+ * ixtts_ln_modulate_f32    replaces FinalLayer's `modulate(norm_final(x), shift, scale)` (diffusion_transformer.py:83-100):
+ *     out = layer_norm(x, eps, no affine) * (1 + ss[b,H:2H]) + ss[b,0:H], ss = adaLN_modulation(c) [B,2H] (shift | scale).
+ * ixtts_rope_qk_f32        replaces apply_rotary_emb on q and k (gpt_fast/model.py:289-301,348-360), in place on the
+ *     wqkv output [B*T,3H]: pair i of head h at columns h*hd+2i,+1 is multiplied by cos_sin[t][i] = (cos, sin).
+ * ixtts_swiglu_f32         replaces `F.silu(w1(x)) * w3(x)` (gpt_fast/model.py:316-326) on the fused [w1; w3] GEMM
+ *     output u [rows,2F]: out[r,j] = silu(u[r,j]) * u[r,F+j].
+ * ixtts_wn_gate_f32        replaces fused_add_tanh_sigmoid_multiply (wavenet.py:142-160): out[b,c,t] =
+ *     tanh(a[b,c,t] + g[b,off+c]) * sigmoid(a[b,C+c,t] + g[b,off+C+c]); a [B,2C,T], g [B,g_stride], out [B,C,T].
+ * All tensors contiguous fp32 device memory; H, F multiples of 4, H <= 2048.
+ */
+int ixtts_adaln_rmsnorm_f32(const float* x_dev, const float* wb_dev, const float* g_dev, float* out_dev, int B, int T, int H, float eps,
+                            void* stream);
+int ixtts_ln_modulate_f32(const float* x_dev, const float* shift_scale_dev, float* out_dev, int B, int T, int H, float eps, void* stream);
+int ixtts_rope_qk_f32(float* qkv_dev, const float* cos_sin_dev, int B, int T, int H, int head_dim, void* stream);
+int ixtts_swiglu_f32(const float* u_dev, float* out_dev, long rows, int F, void* stream);
+int ixtts_wn_gate_f32(const float* a_dev, const float* g_dev, float* out_dev, int B, int C, int T, long g_stride, int g_offset, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Seam 2 -- BigVGAN-v2 generator
  * replaces: `BigVGAN.__init__/remove_weight_norm/forward`

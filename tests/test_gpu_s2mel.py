@@ -5,6 +5,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def dev():
+    return torch.device("cuda:0")
+
+
 def test_s2mel_on_gpu_vs_reference_fixture(golden):
     import voice_tts_amd.s2mel as S2
 
@@ -40,3 +45,43 @@ def test_attn_full_f32_vs_torch_sdpa(B, H, T):
     out2 = attn_full(q2, k2, v2)
     ref2 = torch.nn.functional.scaled_dot_product_attention(q2.transpose(1, 2), k2.transpose(1, 2), v2.transpose(1, 2)).transpose(1, 2)
     assert (out2 - ref2).abs().max().item() <= 2e-5 * max(1.0, ref2.abs().max().item())
+
+
+def test_dit_row_ops_match_torch(dev):
+    """csrc/dit_ops.hip against the torch formulas they replace (the CPU branch of the same functions), fp32, <= 2e-6 * max."""
+    from voice_tts_amd import s2mel as S
+
+    g = torch.Generator().manual_seed(11)
+    B, T, H, Fd = 2, 37, 512, 1536
+    x = torch.randn(B, T, H, generator=g) * 3 + 0.5
+    wb = torch.randn(B, 2 * H, generator=g)
+    gain = 1 + 0.1 * torch.randn(H, generator=g)
+    u = torch.randn(B * T, 2 * Fd, generator=g) * 2
+    a = torch.randn(B, 2 * 64, 53, generator=g) * 2
+    gv = torch.randn(B, 3 * 128, generator=g)
+
+    def close(got, want, what):
+        err = (got.cpu() - want).abs().max().item()
+        assert err <= 2e-6 * max(1.0, want.abs().max().item()), (what, err)
+
+    close(S.adaln_rmsnorm(x.to(dev), wb.to(dev), gain.to(dev)), S.adaln_rmsnorm(x, wb, gain), "adaln_rmsnorm")
+    close(S.ln_modulate(x.to(dev), wb.to(dev)), S.ln_modulate(x, wb), "ln_modulate")
+    close(S.swiglu(u.to(dev)), S.swiglu(u), "swiglu")
+    close(S.wn_gate(a.to(dev), gv.to(dev), 128, 64), S.wn_gate(a, gv, 128, 64), "wn_gate")
+    # tiny hidden size: rows shorter than a wavefront's 64 float4
+    xs, wbs, gs = torch.randn(1, 5, 64, generator=g), torch.randn(1, 128, generator=g), torch.ones(64)
+    close(S.adaln_rmsnorm(xs.to(dev), wbs.to(dev), gs.to(dev)), S.adaln_rmsnorm(xs, wbs, gs), "adaln_rmsnorm H=64")
+
+
+def test_rope_attention_path_matches_torch(dev):
+    """In-place RoPE on the wqkv output + the flash kernel on strided views == complex-multiply RoPE + SDPA (the CPU branch)."""
+    from voice_tts_amd.s2mel import S2Mel, make_s2mel_weights, tiny_s2mel_cfg
+
+    cfg = tiny_s2mel_cfg(hidden_dim=128, num_heads=2, wavenet_hidden=128)  # head_dim 64: the HIP path is taken
+    W = make_s2mel_weights(cfg, seed=5)
+    cpu, gpu = S2Mel(W, cfg, "cpu"), S2Mel(W, cfg, dev)
+    B, T, H = 2, 150, 128
+    qkv = torch.randn(B * T, 3 * H, generator=torch.Generator().manual_seed(3))
+    want = cpu._attention(qkv.clone(), B, T, None)
+    got = gpu._attention(qkv.clone().to(dev), B, T, None).cpu()
+    assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())

@@ -46,6 +46,11 @@ SYMBOLS = {
     "ixtts_aa_snake_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ixtts_attn_full_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_long, C.c_long,
                                       C.c_long, C.c_float, _P]),
+    "ixtts_adaln_rmsnorm_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
+    "ixtts_ln_modulate_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
+    "ixtts_rope_qk_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ixtts_swiglu_f32": (C.c_int, [_P, _P, C.c_long, C.c_int, _P]),
+    "ixtts_wn_gate_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, _P]),
     "ixtts_bigvgan_create": (C.c_int, [C.POINTER(_P), C.POINTER(BigVGANCfg)]),
     "ixtts_bigvgan_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int]),
     "ixtts_bigvgan_finalize": (C.c_int, [_P]),

@@ -126,7 +126,7 @@ def attn_full(q, k, v, scale=None):
     B, T, Hh, d = q.shape
     assert d == 64 and q.is_cuda and q.dtype == torch.float32 and k.shape == q.shape and v.shape == q.shape
     for t in (q, k, v):
-        assert t.stride(3) == 1 and t.stride() == q.stride()
+        assert t.stride(3) == 1 and t.stride() == q.stride() and t.stride(1) % 4 == 0 and t.data_ptr() % 16 == 0
     out = torch.empty(B, T, Hh, d, device=q.device, dtype=torch.float32)
     sc = float(scale if scale is not None else 1.0 / math.sqrt(d))
     with torch.cuda.device(q.device):
@@ -140,6 +140,69 @@ def _lin(x, W, name):
     return F.linear(x, W[name + ".weight"], W.get(name + ".bias"))
 
 
+# ---------------------------------------------------------------------------------- fused row / element ops
+# On the GPU these are single HIP passes (csrc/dit_ops.hip, declared in include/ixtts_hip.h); on the CPU (parity tests
+# against the reference's modules) the same arithmetic in torch.
+def _hip_call(name, *args):
+    from . import _lib
+
+    _lib.check(getattr(_lib.lib(), name)(*args, _lib.current_stream_ptr()), name)
+
+
+def adaln_rmsnorm(x, wb, g, eps=1e-5):
+    """AdaptiveLayerNorm over RMSNorm (gpt_fast/model.py:18-37,362-372): x [B,T,H], wb = project_layer(c) [B,2H] (weight | bias)."""
+    B, T, H = x.shape
+    if x.is_cuda:
+        import ctypes as C
+
+        x, wb = x.contiguous(), wb.contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _hip_call("ixtts_adaln_rmsnorm_f32", x.data_ptr(), wb.data_ptr(), g.data_ptr(), out.data_ptr(), B, T, H, C.c_float(eps))
+        return out
+    w, b = wb[:, None, :H], wb[:, None, H:]
+    return torch.addcmul(b, w, F.rms_norm(x, (H,), g, eps))
+
+
+def ln_modulate(x, ss, eps=1e-6):
+    """FinalLayer: layer_norm(x, no affine) * (1 + scale) + shift, ss = adaLN_modulation(c) [B,2H] = (shift | scale)."""
+    B, T, H = x.shape
+    if x.is_cuda:
+        import ctypes as C
+
+        x, ss = x.contiguous(), ss.contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _hip_call("ixtts_ln_modulate_f32", x.data_ptr(), ss.data_ptr(), out.data_ptr(), B, T, H, C.c_float(eps))
+        return out
+    return F.layer_norm(x, (H,), None, None, eps) * (1 + ss[:, None, H:]) + ss[:, None, :H]
+
+
+def swiglu(u):
+    """silu(u[..., :F]) * u[..., F:] on the fused [w1; w3] GEMM output (gpt_fast/model.py:316-326)."""
+    Fd = u.shape[-1] // 2
+    if u.is_cuda:
+        u = u.contiguous()
+        out = torch.empty(*u.shape[:-1], Fd, device=u.device, dtype=u.dtype)
+        with torch.cuda.device(u.device):
+            _hip_call("ixtts_swiglu_f32", u.data_ptr(), out.data_ptr(), u.numel() // (2 * Fd), Fd)
+        return out
+    return F.silu(u[..., :Fd]) * u[..., Fd:]
+
+
+def wn_gate(a, g, off, C_):
+    """tanh(a[:, :C] + g_a) * sigmoid(a[:, C:] + g_b) with (g_a | g_b) = g[:, off:off+2C] (wavenet.py:142-160)."""
+    B, _, T = a.shape
+    if a.is_cuda:
+        a, g = a.contiguous(), g.contiguous()
+        out = torch.empty(B, C_, T, device=a.device, dtype=a.dtype)
+        with torch.cuda.device(a.device):
+            _hip_call("ixtts_wn_gate_f32", a.data_ptr(), g.data_ptr(), out.data_ptr(), B, C_, T, g.shape[1], off)
+        return out
+    x = a + g[:, off:off + 2 * C_, None]
+    return torch.tanh(x[:, :C_]) * torch.sigmoid(x[:, C_:])
+
+
 class S2Mel:
     def __init__(self, W, cfg=S2MEL_CFG, device="cpu"):
         self.cfg = dict(cfg)
@@ -151,6 +214,19 @@ class S2Mel:
         half = 128
         self.t_freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half).to(self.device)
         self._rope = None
+        # derived weights (exact re-arrangements: concatenations / column splits of the reference's matrices)
+        W, C_, L = self.W, cfg["in_channels"], cfg["depth"]
+        t = "cfm.estimator.transformer."
+        self.w13 = [torch.cat([W[t + f"layers.{i}.feed_forward.w1.weight"], W[t + f"layers.{i}.feed_forward.w3.weight"]], 0).contiguous() for i in range(L)]
+        self.skip_w = {i: (W[t + f"layers.{i}.skip_in_linear.weight"][:, :H].contiguous(), W[t + f"layers.{i}.skip_in_linear.weight"][:, H:].contiguous())
+                       for i in range(L // 2 + 1, L)}
+        names = [t + f"layers.{i}.{n}" for i in range(L) for n in ("attention_norm", "ffn_norm")] + [t + "norm"]
+        self.proj_w = torch.cat([W[n + ".project_layer.weight"] for n in names], 0).contiguous()  # every AdaLN projection of a step: one GEMM
+        self.proj_b = torch.cat([W[n + ".project_layer.bias"] for n in names], 0).contiguous()
+        mw = W["cfm.estimator.cond_x_merge_linear.weight"]  # input = [x (C) | prompt_x (C) | cond (H) | style]
+        self.merge_x, self.merge_rest = mw[:, :C_].contiguous(), mw[:, C_:].contiguous()
+        sw = W["cfm.estimator.skip_linear.weight"]  # input = [x_res (H) | x (C)]
+        self.skipl_res, self.skipl_x = sw[:, :H].contiguous(), sw[:, H:].contiguous()
 
     # ------------------------------------------------------------------ small pieces
     def gpt_layer(self, latent):
@@ -200,95 +276,114 @@ class S2Mel:
         xc = torch.view_as_complex(x.reshape(*x.shape[:-1], -1, 2))
         return torch.view_as_real(xc * fc.view(1, fc.shape[0], 1, fc.shape[1])).flatten(3)
 
-    def _ada_norm(self, x, c, prefix):
-        """AdaptiveLayerNorm(RMSNorm): weight * (rms(x) * g) + bias with (weight, bias) = project_layer(c)."""
-        W = self.W
-        wb = _lin(c, W, prefix + ".project_layer")
-        H = x.shape[-1]
-        w, b = wb[..., :H], wb[..., H:]
-        n = F.rms_norm(x, (H,), W[prefix + ".norm.weight"], 1e-5)
-        return torch.addcmul(b, w, n)
+    def _attention(self, qkv, B, T, mask):
+        """RoPE on q, k + softmax(q k^T / sqrt(d)) v (gpt_fast/model.py:289-312).  qkv [B*T, 3H] -> [B*T, H]."""
+        H, nh, hd = self.cfg["hidden_dim"], self.cfg["num_heads"], self.head_dim
+        fc = self._rope_cache(T)
+        if mask is None and hd == 64 and qkv.is_cuda:
+            # in-place rotation on the GEMM output, then the fp32-MFMA flash kernel on strided views of it: no copies
+            with torch.cuda.device(qkv.device):
+                _hip_call("ixtts_rope_qk_f32", qkv.data_ptr(), torch.view_as_real(fc).data_ptr(), B, T, H, hd)
+            v4 = qkv.view(B, T, 3, nh, hd)
+            return attn_full(v4[:, :, 0], v4[:, :, 1], v4[:, :, 2]).reshape(B * T, H)
+        q, k, v = qkv.view(B, T, 3 * H).split([H, H, H], dim=-1)
+        q = self._rotary(q.reshape(B, T, nh, hd), fc)
+        k = self._rotary(k.reshape(B, T, nh, hd), fc)
+        v = v.reshape(B, T, nh, hd)
+        y = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=mask, dropout_p=0.0)
+        return y.transpose(1, 2).reshape(B * T, H)
 
     def _transformer(self, x, c, mask):
+        """Transformer.forward with U-ViT skips (gpt_fast/model.py:167-207): x [B,T,H], c [B,H] -> [B,T,H].  Residual adds
+        ride in the GEMM epilogues (addmm), [w1; w3] is one GEMM, the skip concat is two accumulated GEMMs."""
         W, cfg = self.W, self.cfg
         B, T, H = x.shape
-        nh, hd = cfg["num_heads"], self.head_dim
-        fc = self._rope_cache(T)
         L = cfg["depth"]
+        wb_all = F.linear(c, self.proj_w, self.proj_b).view(B, 2 * L + 1, 2 * H)  # (weight | bias) of every AdaLN
+        x = x.reshape(B * T, H)
         skips = []
         for i in range(L):
             p = f"cfm.estimator.transformer.layers.{i}."
             if i > L // 2:
-                x = _lin(torch.cat([x, skips.pop()], dim=-1), W, p + "skip_in_linear")
-            a = self._ada_norm(x, c, p + "attention_norm")
-            q, k, v = F.linear(a, W[p + "attention.wqkv.weight"]).split([H, H, H], dim=-1)
-            q = self._rotary(q.view(B, T, nh, hd), fc)
-            k = self._rotary(k.view(B, T, nh, hd), fc)
-            v = v.reshape(B, T, nh, hd)
-            if mask is None and hd == 64 and x.is_cuda:
-                y = attn_full(q.contiguous(), k.contiguous(), v.contiguous()).reshape(B, T, H)  # HIP fp32-MFMA flash kernel
-            else:
-                y = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=mask, dropout_p=0.0)
-                y = y.transpose(1, 2).reshape(B, T, H)
-            h = x + F.linear(y, W[p + "attention.wo.weight"])
-            f = self._ada_norm(h, c, p + "ffn_norm")
-            x = h + F.linear(F.silu(F.linear(f, W[p + "feed_forward.w1.weight"])) * F.linear(f, W[p + "feed_forward.w3.weight"]), W[p + "feed_forward.w2.weight"])
+                wa, wb_ = self.skip_w[i]
+                x = torch.addmm(F.linear(skips.pop(), wb_, W[p + "skip_in_linear.bias"]), x, wa.t())
+            a = adaln_rmsnorm(x.view(B, T, H), wb_all[:, 2 * i], W[p + "attention_norm.norm.weight"])
+            y = self._attention(F.linear(a.view(B * T, H), W[p + "attention.wqkv.weight"]), B, T, mask)
+            h = torch.addmm(x, y, W[p + "attention.wo.weight"].t())
+            f = adaln_rmsnorm(h.view(B, T, H), wb_all[:, 2 * i + 1], W[p + "ffn_norm.norm.weight"])
+            x = torch.addmm(h, swiglu(F.linear(f.view(B * T, H), self.w13[i])), W[p + "feed_forward.w2.weight"].t())
             if i < L // 2:
                 skips.append(x)
-        return self._ada_norm(x, c, "cfm.estimator.transformer.norm")
+        return adaln_rmsnorm(x.view(B, T, H), wb_all[:, 2 * L], W["cfm.estimator.transformer.norm.norm.weight"])
 
-    def _wavenet(self, x, x_mask, g):
-        """WN.forward: reflect-padded dilated convs, tanh*sigmoid gate, residual/skip split (wavenet.py:142-167)."""
+    def _wavenet(self, x, x_mask, g, full):
+        """WN.forward: reflect-padded dilated convs, tanh*sigmoid gate, residual/skip split (wavenet.py:142-167).
+        x [B,Hw,T]; g [B,Hw] (timestep embedding); `full`: every sequence spans T, so the mask multiplies are identities."""
         W, cfg = self.W, self.cfg
         Hw, nl, k = cfg["wavenet_hidden"], cfg["wavenet_layers"], cfg["wavenet_kernel"]
         p = "cfm.estimator.wavenet."
-        g = F.conv1d(g, W[p + "cond_layer.conv.conv.weight"], W[p + "cond_layer.conv.conv.bias"])
-        out = torch.zeros_like(x)
+        g = F.linear(g, W[p + "cond_layer.conv.conv.weight"][:, :, 0], W[p + "cond_layer.conv.conv.bias"])  # 1x1 conv on a length-1 signal
+        out = None
         for i in range(nl):
             d = cfg["wavenet_dilation_rate"] ** i
             tot = (k - 1) * d
             right = tot // 2
             xin = _pad_reflect(x, tot - right, right)  # SConv1d non-causal: left = total - total//2 (encodec.py:224-227)
             xin = F.conv1d(xin, W[p + f"in_layers.{i}.conv.conv.weight"], W[p + f"in_layers.{i}.conv.conv.bias"], dilation=d)
-            a = xin + g[:, i * 2 * Hw:(i + 1) * 2 * Hw, :]
-            acts = torch.tanh(a[:, :Hw]) * torch.sigmoid(a[:, Hw:])
+            acts = wn_gate(xin, g, i * 2 * Hw, Hw)
             rs = F.conv1d(acts, W[p + f"res_skip_layers.{i}.conv.conv.weight"], W[p + f"res_skip_layers.{i}.conv.conv.bias"])
             if i < nl - 1:
-                x = (x + rs[:, :Hw]) * x_mask
-                out = out + rs[:, Hw:]
+                x = x + rs[:, :Hw]
+                if not full:
+                    x = x * x_mask
+                out = rs[:, Hw:] if out is None else out + rs[:, Hw:]
             else:
-                out = out + rs
-        return out * x_mask
+                out = rs if out is None else out + rs
+        return out if full else out * x_mask
 
     # ------------------------------------------------------------------ DiT + CFM
-    def dit(self, x, prompt_x, x_lens, t, style, cond):
-        """DiT.forward, eval mode (diffusion_transformer.py:186-257).  x, prompt_x [B,80,T]; cond [B,T,content]."""
+    def dit_prepare(self, prompt_x, x_lens, style, cond):
+        """Everything of DiT.forward that does not depend on (x, t): computed once per CFM solve instead of once per
+        Euler step.  prompt_x [B,80,T]; cond [B,T,content]; style [B,style_dim]."""
         W = self.W
         e = "cfm.estimator."
-        B, _, T = x.shape
-        t1 = self._t_embed(t, e + "t_embedder")
+        B, _, T = prompt_x.shape
         cond = _lin(cond, W, e + "cond_projection")
-        xt = x.transpose(1, 2)
-        x_in = torch.cat([xt, prompt_x.transpose(1, 2), cond, style[:, None, :].repeat(1, T, 1)], dim=-1)
-        x_in = _lin(x_in, W, e + "cond_x_merge_linear")
-        x_mask = (torch.arange(T, device=x.device).unsqueeze(0) < x_lens.unsqueeze(1)).unsqueeze(1)  # [B,1,T]
-        if int(x_lens.min()) >= T:
+        rest = torch.cat([prompt_x.transpose(1, 2), cond, style[:, None, :].expand(B, T, style.shape[-1])], dim=-1)
+        base = F.linear(rest, self.merge_rest, W[e + "cond_x_merge_linear.bias"])  # cond_x_merge_linear minus its x columns
+        x_mask = (torch.arange(T, device=prompt_x.device).unsqueeze(0) < x_lens.unsqueeze(1)).unsqueeze(1)  # [B,1,T]
+        full = int(x_lens.min()) >= T
+        if full:
             attn_mask = None  # the pipeline always runs one full-length sequence: an all-true key mask is no mask
         else:
             attn_mask = x_mask[:, None, :].expand(x_mask.shape[0], 1, T, T)
             if attn_mask.shape[0] != B:
                 attn_mask = attn_mask.expand(B, 1, T, T)
-        x_res = self._transformer(x_in, t1.unsqueeze(1), attn_mask)
-        x_res = _lin(torch.cat([x_res, xt], dim=-1), W, e + "skip_linear")
+        return dict(B=B, T=T, base=base, x_mask=x_mask.to(base.dtype), attn_mask=attn_mask, full=full)
+
+    def dit_step(self, ctx, x, t):
+        """The (x, t)-dependent part of DiT.forward (diffusion_transformer.py:186-257).  x [B,80,T] or [1,80,T] shared by
+        the whole batch (the CFG stack feeds the same x to both branches); t [B]."""
+        W = self.W
+        e = "cfm.estimator."
+        B, T, base = ctx["B"], ctx["T"], ctx["base"]
+        Hw = self.cfg["wavenet_hidden"]
+        xt = x.transpose(1, 2)  # [Bx,T,80]
+        t1 = self._t_embed(t, e + "t_embedder")
+        x_in = base + F.linear(xt, self.merge_x)  # broadcasts a shared x over the batch
+        x_res = self._transformer(x_in, t1, ctx["attn_mask"])
+        x_res = F.linear(x_res, self.skipl_res, W[e + "skip_linear.bias"]) + F.linear(xt, self.skipl_x)
         h = _lin(x_res, W, e + "conv1").transpose(1, 2)
         t2 = self._t_embed(t, e + "t_embedder2")
-        h = self._wavenet(h, x_mask.to(h.dtype), t2.unsqueeze(2)).transpose(1, 2) + _lin(x_res, W, e + "res_projection")
+        h = self._wavenet(h, ctx["x_mask"], t2, ctx["full"]).transpose(1, 2) + _lin(x_res, W, e + "res_projection")
         ss = _lin(F.silu(t1), W, e + "final_layer.adaLN_modulation.1")
-        Hw = self.cfg["wavenet_hidden"]
-        shift, scale = ss[:, :Hw], ss[:, Hw:]
-        h = F.layer_norm(h, (Hw,), None, None, 1e-6) * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
+        h = ln_modulate(h, ss)
         h = _lin(h, W, e + "final_layer.linear").transpose(1, 2)
         return F.conv1d(h, W[e + "conv2.weight"], W[e + "conv2.bias"])
+
+    def dit(self, x, prompt_x, x_lens, t, style, cond):
+        """DiT.forward, eval mode.  x, prompt_x [B,80,T]; cond [B,T,content]."""
+        return self.dit_step(self.dit_prepare(prompt_x, x_lens, style, cond), x, t)
 
     @torch.no_grad()
     def cfm_inference(self, mu, x_lens, prompt, style, n_timesteps=25, inference_cfg_rate=0.7, noise=None, temperature=1.0):
@@ -302,18 +397,21 @@ class S2Mel:
         prompt_x = torch.zeros_like(x)
         prompt_x[..., :Tp] = prompt[..., :Tp]
         x[..., :Tp] = 0
+        if inference_cfg_rate > 0:
+            # batch-2 stacking of the conditional and the null branch (the reference supports B == 1 only:
+            # its stacked_t has 2 entries whatever B is, flow_matching.py:88-93); x is shared by the two
+            ctx = self.dit_prepare(torch.cat([prompt_x, torch.zeros_like(prompt_x)], 0), x_lens, torch.cat([style, torch.zeros_like(style)], 0),
+                                   torch.cat([mu, torch.zeros_like(mu)], 0))
+        else:
+            ctx = self.dit_prepare(prompt_x, x_lens, style, mu)
         t = t_span[0]
         for step in range(1, len(t_span)):
             dt = t_span[step] - t_span[step - 1]
             if inference_cfg_rate > 0:
-                # batch-2 stacking of the conditional and the null branch (the reference supports B == 1 only:
-                # its stacked_t has 2 entries whatever B is, flow_matching.py:88-93)
-                d = self.dit(torch.cat([x, x], 0), torch.cat([prompt_x, torch.zeros_like(prompt_x)], 0), x_lens, torch.stack([t, t]),
-                             torch.cat([style, torch.zeros_like(style)], 0), torch.cat([mu, torch.zeros_like(mu)], 0))
-                dphi, cfg_dphi = d.chunk(2, dim=0)
-                dphi = (1.0 + inference_cfg_rate) * dphi - inference_cfg_rate * cfg_dphi
+                d = self.dit_step(ctx, x, torch.stack([t, t]))
+                dphi = (1.0 + inference_cfg_rate) * d[0:1] - inference_cfg_rate * d[1:2]
             else:
-                dphi = self.dit(x, prompt_x, x_lens, t.expand(B), style, mu)
+                dphi = self.dit_step(ctx, x, t.expand(B))
             x = x + dt * dphi
             t = t + dt
             x[:, :, :Tp] = 0
