@@ -23,7 +23,9 @@ constexpr int AF_D = 64;        // head dim
 constexpr int AF_KT = 64;       // keys per tile
 constexpr int AF_QW = 32;       // queries per wave
 constexpr int AF_WAVES = 2;
-constexpr int AF_KP = AF_D + 1;  // K tile pitch (floats): lanes of a half-wave read 32 different keys -> odd pitch
+// K tile pitch (floats): rows stay 16-byte aligned (ds_write_b128 / ds_read_b128) and 8 consecutive keys start 17
+// granules apart -> the 8 lanes a b128 read serves per cycle hit 8 different granules mod 8: conflict-free
+constexpr int AF_KP = AF_D + 4;
 
 struct AttnFullArgs {
   const float* q;  // element (b, t, h, d) at q[b*sb + t*st + h*sh + d]
@@ -36,9 +38,11 @@ struct AttnFullArgs {
   float scale;
 };
 
+// The contraction index of S^T = K Q^T is free to permute: k-step kk = 4m + i of lane half lh uses d = 8m + 4 lh + i, so a
+// lane's four consecutive k-steps are one 16-byte LDS read of K (and one 16-byte global read of Q).
 __global__ __launch_bounds__(AF_WAVES * 64) void attn_full_f32_kernel(AttnFullArgs a) {
-  __shared__ float Ks[AF_KT * AF_KP];
-  __shared__ float Vs[AF_KT * AF_D];
+  __shared__ __attribute__((aligned(16))) float Ks[AF_KT * AF_KP];
+  __shared__ __attribute__((aligned(16))) float Vs[AF_KT * AF_D];
   const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -47,69 +51,88 @@ __global__ __launch_bounds__(AF_WAVES * 64) void attn_full_f32_kernel(AttnFullAr
   const float* kb = a.k + b * a.sb + h * a.sh;
   const float* vb = a.v + b * a.sb + h * a.sh;
 
-  // Q^T as the B operand of S^T = K Q^T: lane holds Q[query l31][d = 2*kk + lh], pre-scaled
+  // Q^T as the B operand of S^T = K Q^T: lane holds Q[query l31][d = 8m + 4 lh + i] for k-step 4m + i, pre-scaled
   float qr[AF_D / 2];
   {
     const int qi = min(q0 + l31, a.T - 1);
-    const float* qp = qb + (long)qi * a.st + lh;
+    const float* qp = qb + (long)qi * a.st + 4 * lh;
     // scores are kept in the log2 domain (q pre-scaled by scale * log2 e): softmax weights are one v_exp_f32 each
     const float qs = a.scale * 1.4426950408889634f;
 #pragma unroll
-    for (int kk = 0; kk < AF_D / 2; ++kk) qr[kk] = qp[2 * kk] * qs;
+    for (int m = 0; m < AF_D / 8; ++m) {
+      const float4 t = *reinterpret_cast<const float4*>(qp + 8 * m);
+      qr[4 * m] = t.x * qs; qr[4 * m + 1] = t.y * qs; qr[4 * m + 2] = t.z * qs; qr[4 * m + 3] = t.w * qs;
+    }
   }
   f32x16 ot[2];  // O^T tiles: d 0..31, 32..63 (rows d in registers, column = this lane's query)
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[j][r] = 0.f;
-  float m = -INFINITY, l = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
 
   for (int t0 = 0; t0 < a.T; t0 += AF_KT) {
     __syncthreads();
-    // stage K and V tiles (64 keys x 64 dims): each thread moves 8 float4 of each
+    // stage K and V tiles (64 keys x 64 dims): each thread moves 8 float4 of each.  (Measured r01: issuing these loads one
+    // tile ahead and holding them in registers across the MFMAs is slower, 442 vs 362 us -- 64 more live VGPRs; 4-wave
+    // workgroups halve the staging per flop but leave 304 workgroups for 256 CUs, 404 us.)
 #pragma unroll
     for (int i = 0; i < (AF_KT * AF_D / 4) / (AF_WAVES * 64); ++i) {
       const int idx = threadIdx.x + i * (AF_WAVES * 64);
       const int key = idx >> 4, c4 = idx & 15;
-      const int t = t0 + key;
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < a.T) {
-        kv = *reinterpret_cast<const float4*>(kb + (long)t * a.st + c4 * 4);
-        vv = *reinterpret_cast<const float4*>(vb + (long)t * a.st + c4 * 4);
-      }
-      float* kd = Ks + key * AF_KP + c4 * 4;
-      kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+      const int t = min(t0 + key, a.T - 1);  // rows beyond T repeat the last one (finite); their scores are masked below
+      const float4 kv = *reinterpret_cast<const float4*>(kb + (long)t * a.st + c4 * 4);
+      const float4 vv = *reinterpret_cast<const float4*>(vb + (long)t * a.st + c4 * 4);
+      *reinterpret_cast<float4*>(Ks + key * AF_KP + c4 * 4) = kv;
       *reinterpret_cast<float4*>(Vs + key * AF_D + c4 * 4) = vv;
     }
     __syncthreads();
 
-    // ---- S^T = K Q^T for the two 32-key halves of the tile
+    // ---- S^T = K Q^T for the two 32-key halves of the tile; A operands one 16-byte read per four k-steps, read one
+    //      group ahead of the MFMAs that consume them
     f32x16 st[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[j][r] = 0.f;
+    const float* kp0 = Ks + l31 * AF_KP + 4 * lh;
+    const float* kp1 = kp0 + 32 * AF_KP;
+    float4 ka[2][2];
+    ka[0][0] = *reinterpret_cast<const float4*>(kp0);
+    ka[0][1] = *reinterpret_cast<const float4*>(kp1);
 #pragma unroll
-    for (int kk = 0; kk < AF_D / 2; ++kk) {
+    for (int m = 0; m < AF_D / 8; ++m) {
+      if (m + 1 < AF_D / 8) {
+        ka[(m + 1) & 1][0] = *reinterpret_cast<const float4*>(kp0 + 8 * (m + 1));
+        ka[(m + 1) & 1][1] = *reinterpret_cast<const float4*>(kp1 + 8 * (m + 1));
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const float ka = Ks[(j * 32 + l31) * AF_KP + 2 * kk + lh];  // A[i = key][k = d]
-        st[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka, qr[kk], st[j], 0, 0, 0);
+        const float4 kk4 = ka[m & 1][j];
+        st[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk4.x, qr[4 * m], st[j], 0, 0, 0);
+        st[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk4.y, qr[4 * m + 1], st[j], 0, 0, 0);
+        st[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk4.z, qr[4 * m + 2], st[j], 0, 0, 0);
+        st[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk4.w, qr[4 * m + 3], st[j], 0, 0, 0);
       }
     }
-    // ---- online softmax for this lane's query; keys beyond T are masked
+    // ---- online softmax for this lane's query; keys beyond T are masked (only the last tile has any)
+    if (t0 + AF_KT > a.T) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= a.T) st[j][r] = -INFINITY;
+        }
+    }
     float tmax = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = t0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (key >= a.T) st[j][r] = -INFINITY;
-        tmax = fmaxf(tmax, st[j][r]);
-      }
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, st[j][r]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float mn = fmaxf(m, tmax);
-    const float alpha = __builtin_amdgcn_exp2f(m - mn);  // 0 on the first tile (m = -inf)
+    const float mn = fmaxf(m_run, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - mn);  // 0 on the first tile (m = -inf)
     float psum = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -120,28 +143,38 @@ __global__ __launch_bounds__(AF_WAVES * 64) void attn_full_f32_kernel(AttnFullAr
         psum += p;
       }
     psum += __shfl_xor(psum, 32, 64);
-    l = l * alpha + psum;
-    m = mn;
+    l_run = l_run * alpha + psum;
+    m_run = mn;
+    if (alpha != 1.0f) {  // (per lane; a stable running maximum leaves O^T untouched)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ot[j][r] *= alpha;
-    // ---- O^T += V^T P^T : k-step (j, r) pairs key (r&3)+8(r>>2) [lanes 0-31] with that key + 4 [lanes 32-63]
+        for (int r = 0; r < 16; ++r) ot[j][r] *= alpha;
+    }
+    // ---- O^T += V^T P^T : k-step (j, r) pairs key (r&3)+8(r>>2) [lanes 0-31] with that key + 4 [lanes 32-63];
+    //      the two A operands of a step are read one step ahead
+    const float* vp = Vs + (4 * lh) * AF_D + l31;
+    float va[2][2];
+    va[0][0] = vp[0];
+    va[0][1] = vp[32];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float* vrow = Vs + key * AF_D + l31;  // A[i = d][k = key]
-        const float pv = st[j][r];                  // B[k = key][j = query]
-        ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], pv, ot[0], 0, 0, 0);
-        ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], pv, ot[1], 0, 0, 0);
+    for (int s = 0; s < 32; ++s) {
+      const int j = s >> 4, r = s & 15;
+      if (s + 1 < 32) {
+        const int j1 = (s + 1) >> 4, r1 = (s + 1) & 15;
+        const float* vrow = vp + (j1 * 32 + (r1 & 3) + 8 * (r1 >> 2)) * AF_D;
+        va[(s + 1) & 1][0] = vrow[0];
+        va[(s + 1) & 1][1] = vrow[32];
       }
+      const float pv = st[j][r];  // B[k = key][j = query]
+      ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s & 1][0], pv, ot[0], 0, 0, 0);
+      ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s & 1][1], pv, ot[1], 0, 0, 0);
+    }
   }
   // ---- normalise and store: lane's query column, d rows in registers
   const int qi = q0 + l31;
   if (qi < a.T) {
-    const float inv = 1.0f / l;
+    const float inv = 1.0f / l_run;
     float* op = a.o + b * a.osb + (long)qi * a.ost + h * a.osh;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
