@@ -44,8 +44,9 @@ SYMBOLS = {
     "ixtts_version": (C.c_char_p, []),
     "ixtts_last_error": (C.c_char_p, []),
     "ixtts_aa_snake_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "ixtts_attn_full_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ixtts_attn_full_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_long, C.c_long,
-                                      C.c_long, C.c_float, _P]),
+                                      C.c_long, C.c_float, _P, C.c_size_t, _P]),
     "ixtts_adaln_rmsnorm_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "ixtts_ln_modulate_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "ixtts_rope_qk_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

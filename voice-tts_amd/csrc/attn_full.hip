@@ -23,6 +23,7 @@ constexpr int AF_D = 64;        // head dim
 constexpr int AF_KT = 64;       // keys per tile
 constexpr int AF_QW = 32;       // queries per wave
 constexpr int AF_WAVES = 2;
+constexpr int AF_KSPLIT = 3;   // key-range splits when the grid is too small (see attn_full_f32_kernel)
 // K tile pitch (floats): rows stay 16-byte aligned (ds_write_b128 / ds_read_b128) and 8 consecutive keys start 17
 // granules apart -> the 8 lanes a b128 read serves per cycle hit 8 different granules mod 8: conflict-free
 constexpr int AF_KP = AF_D + 4;
@@ -36,10 +37,16 @@ struct AttnFullArgs {
   long osb, ost, osh;    // output strides
   int B, H, T;
   float scale;
+  float* ws_o;   // KSPLIT > 1: un-normalised partial outputs [split][B][H][T][64]
+  float* ws_ml;  //             and their (running max in log2 units, sum) [split][B][H][T][2]
 };
 
 // The contraction index of S^T = K Q^T is free to permute: k-step kk = 4m + i of lane half lh uses d = 8m + 4 lh + i, so a
 // lane's four consecutive k-steps are one 16-byte LDS read of K (and one 16-byte global read of Q).
+// KSPLIT > 1: blockIdx.z owns a contiguous share of the key tiles and leaves an un-normalised partial; with
+// T = 2322 a (batch, head) has only 73 32-query wave tasks -- 1184 waves for 1024 SIMDs -- so one wave per SIMD cannot hide
+// its own LDS / softmax / staging latencies (r01 PMC: 0.88 resident waves per SIMD on average, MFMA busy 40 %).
+template <int KSPLIT>
 __global__ __launch_bounds__(AF_WAVES * 64) void attn_full_f32_kernel(AttnFullArgs a) {
   __shared__ __attribute__((aligned(16))) float Ks[AF_KT * AF_KP];
   __shared__ __attribute__((aligned(16))) float Vs[AF_KT * AF_D];
@@ -71,7 +78,11 @@ __global__ __launch_bounds__(AF_WAVES * 64) void attn_full_f32_kernel(AttnFullAr
     for (int r = 0; r < 16; ++r) ot[j][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  for (int t0 = 0; t0 < a.T; t0 += AF_KT) {
+  const int n_tiles = (a.T + AF_KT - 1) / AF_KT;
+  const int tiles_per = (n_tiles + KSPLIT - 1) / KSPLIT;
+  const int t_lo = (KSPLIT > 1 ? blockIdx.z * tiles_per : 0) * AF_KT;
+  const int t_hi = KSPLIT > 1 ? min(a.T, t_lo + tiles_per * AF_KT) : a.T;
+  for (int t0 = t_lo; t0 < t_hi; t0 += AF_KT) {
     __syncthreads();
     // stage K and V tiles (64 keys x 64 dims): each thread moves 8 float4 of each.  (Measured r01: issuing these loads one
     // tile ahead and holding them in registers across the MFMAs is slower, 442 vs 362 us -- 64 more live VGPRs; 4-wave
@@ -171,23 +182,66 @@ __global__ __launch_bounds__(AF_WAVES * 64) void attn_full_f32_kernel(AttnFullAr
       ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s & 1][1], pv, ot[1], 0, 0, 0);
     }
   }
-  // ---- normalise and store: lane's query column, d rows in registers
   const int qi = q0 + l31;
   if (qi < a.T) {
-    const float inv = 1.0f / l_run;
-    float* op = a.o + b * a.osb + (long)qi * a.ost + h * a.osh;
+    if constexpr (KSPLIT == 1) {
+      // ---- normalise and store: lane's query column, d rows in registers
+      const float inv = 1.0f / l_run;
+      float* op = a.o + b * a.osb + (long)qi * a.ost + h * a.osh;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) op[j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = ot[j][r] * inv;
+        for (int r = 0; r < 16; ++r) op[j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = ot[j][r] * inv;
+    } else {
+      const long row = ((long)blockIdx.z * a.B * a.H + bh) * a.T + qi;
+      float* op = a.ws_o + row * AF_D;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) op[j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = ot[j][r];
+      if (lh == 0) *reinterpret_cast<float2*>(a.ws_ml + row * 2) = make_float2(m_run, l_run);
+    }
   }
+}
+
+// out[b,t,h,:] = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M): one wavefront per (b, h, t) row, lane = dim
+template <int KSPLIT>
+__global__ __launch_bounds__(256) void attn_full_merge_kernel(AttnFullArgs a) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b*H + h)*T + t
+  const long rows = (long)a.B * a.H * a.T;
+  if (row >= rows) return;
+  const int d = threadIdx.x & 63;
+  const int t = (int)(row % a.T);
+  const int bh = (int)(row / a.T), b = bh / a.H, h = bh % a.H;
+  float2 ml[KSPLIT];
+  float o[KSPLIT];
+  float M = -INFINITY;
+#pragma unroll
+  for (int sp = 0; sp < KSPLIT; ++sp) {
+    ml[sp] = *reinterpret_cast<const float2*>(a.ws_ml + ((long)sp * rows + row) * 2);
+    o[sp] = a.ws_o[((long)sp * rows + row) * AF_D + d];
+    M = fmaxf(M, ml[sp].x);
+  }
+  float L = 0.f, O = 0.f;
+#pragma unroll
+  for (int sp = 0; sp < KSPLIT; ++sp) {
+    const float w = (ml[sp].x > -INFINITY) ? __builtin_amdgcn_exp2f(ml[sp].x - M) : 0.f;  // a split without keys has m = -inf, l = 0
+    L = fmaf(ml[sp].y, w, L);
+    O = fmaf(o[sp], w, O);
+  }
+  a.o[b * a.osb + (long)t * a.ost + h * a.osh + d] = O / L;
 }
 
 }  // namespace ixtts
 
+extern "C" size_t ixtts_attn_full_workspace_bytes(int B, int H, int T) {
+  if (B <= 0 || H <= 0 || T <= 0) return 0;
+  return (size_t)ixtts::AF_KSPLIT * B * H * T * (ixtts::AF_D + 2) * sizeof(float);
+}
+
 extern "C" int ixtts_attn_full_f32(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, int B, int H, int T,
                                    int head_dim, long stride_b, long stride_t, long stride_h, long ostride_b, long ostride_t,
-                                   long ostride_h, float scale, void* stream) {
+                                   long ostride_h, float scale, void* workspace_dev, size_t workspace_bytes, void* stream) {
   using namespace ixtts;
   IX_ARG(q_dev && k_dev && v_dev && out_dev, "attn_full: null pointer");
   IX_ARG(head_dim == AF_D, "attn_full: head_dim %d (only 64 is built)", head_dim);
@@ -198,8 +252,21 @@ extern "C" int ixtts_attn_full_f32(const float* q_dev, const float* k_dev, const
   a.sb = stride_b; a.st = stride_t; a.sh = stride_h;
   a.osb = ostride_b; a.ost = ostride_t; a.osh = ostride_h;
   a.B = B; a.H = H; a.T = T; a.scale = scale;
-  dim3 grid(ceil_div(T, AF_WAVES * AF_QW), B * H);
-  hipLaunchKernelGGL(attn_full_f32_kernel, grid, dim3(AF_WAVES * 64), 0, (hipStream_t)stream, a);
+  a.ws_o = a.ws_ml = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  const int qblocks = ceil_div(T, AF_WAVES * AF_QW);
+  // split the keys when the un-split grid cannot give every SIMD two waves and the caller brought the workspace
+  const bool split = workspace_dev && workspace_bytes >= ixtts_attn_full_workspace_bytes(B, H, T) && T > 4 * AF_KT &&
+                     (long)qblocks * B * H * AF_WAVES < 2 * 1024;
+  if (split) {
+    a.ws_o = reinterpret_cast<float*>(workspace_dev);
+    a.ws_ml = a.ws_o + (size_t)AF_KSPLIT * B * H * T * AF_D;
+    hipLaunchKernelGGL(attn_full_f32_kernel<AF_KSPLIT>, dim3(qblocks, B * H, AF_KSPLIT), dim3(AF_WAVES * 64), 0, st, a);
+    const long rows = (long)B * H * T;
+    hipLaunchKernelGGL(attn_full_merge_kernel<AF_KSPLIT>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(attn_full_f32_kernel<1>, dim3(qblocks, B * H), dim3(AF_WAVES * 64), 0, st, a);
+  }
   IX_HIP(hipGetLastError());
   return IXTTS_OK;
 }

@@ -129,9 +129,13 @@ def attn_full(q, k, v, scale=None):
         assert t.stride(3) == 1 and t.stride() == q.stride() and t.stride(1) % 4 == 0 and t.data_ptr() % 16 == 0
     out = torch.empty(B, T, Hh, d, device=q.device, dtype=torch.float32)
     sc = float(scale if scale is not None else 1.0 / math.sqrt(d))
+    L = _lib.lib()
+    nws = L.ixtts_attn_full_workspace_bytes(B, Hh, T)
+    ws = torch.empty(nws, device=q.device, dtype=torch.uint8)  # scratch for the key-split partials (caching allocator: no hipMalloc)
     with torch.cuda.device(q.device):
-        rc = _lib.lib().ixtts_attn_full_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Hh, T, d, q.stride(0), q.stride(1),
-                                            q.stride(2), out.stride(0), out.stride(1), out.stride(2), C.c_float(sc), _lib.current_stream_ptr())
+        rc = L.ixtts_attn_full_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Hh, T, d, q.stride(0), q.stride(1),
+                                   q.stride(2), out.stride(0), out.stride(1), out.stride(2), C.c_float(sc), ws.data_ptr(), nws,
+                                   _lib.current_stream_ptr())
     _lib.check(rc, "ixtts_attn_full_f32")
     return out
 
