@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--codes", type=int, default=1100, help="mel codes per segment (11 per char)")
     ap.add_argument("--segments", type=int, default=2)
     ap.add_argument("--no-s2mel", action="store_true", help="leave the PyTorch-glue s2mel stage out of the timed region (feed synthetic mels)")
+    ap.add_argument("--no-cond", action="store_true", help="leave the conditioning encoders out of the timed region (feed a synthetic conds_latent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -98,6 +99,12 @@ def main():
         import voice_tts_amd.s2mel as S2
 
         hp.attach_s2mel(S2.make_s2mel_weights(S2.S2MEL_CFG, seed=1234))
+    use_cond = not args.no_cond
+    if use_cond:
+        # PyTorch glue stage (row N2): conformer + perceiver conditioning encoders (338 M params, seeded per rank alike)
+        import voice_tts_amd.conditioning as CD
+
+        hp.attach_conditioning(CD.make_cond_weights(CD.COND_CFG, seed=1234))
     if world > 1:
         for t in hp.broadcast_tensors():
             dist.broadcast(t, src=0)
@@ -110,6 +117,8 @@ def main():
     # ---- synthetic request, resident in HBM before the timed region (seeded per rank)
     g = torch.Generator().manual_seed(100 + rank)
     conds = [(torch.randn(34, D, generator=g) * 0.5).to(dev) for _ in range(n_seg)]
+    # 5 s speaker prompt -> 249 w2v-bert frames: stand-in for the cached, normalised layer-17 features
+    spk_cond_emb = torch.randn(1, 249, 1024, generator=g).to(dev)
     texts = [torch.randint(2, 12000, (n_tok,), generator=g) for _ in range(n_seg)]
     mels = [(torch.randn(1, 80, frames, generator=g) * 2 - 4).clamp(-11.5, 2).to(dev) for _ in range(n_seg)]
     # 5 s speaker prompt -> 430 reference mel frames: stand-ins for the cached prompt features
@@ -127,6 +136,12 @@ def main():
             return time.perf_counter()
 
         t0 = tick()
+        if use_cond:  # merge_emovec + get_conditioning (infer_v2.py:629-635, model_v2.py:684-696), once per request
+            cl = hp.conds_from_prompt(spk_cond_emb)
+            # synthetic encoder weights give arbitrary latent statistics; keep the GPT prefix at the scale it is built for
+            cl = cl * (0.5 / cl.std().clamp_min(1e-6))
+            for s in range(n_seg):
+                conds[s] = cl
         prompts = [hp.prepare_gpt_inputs(conds[s], texts[s])[:2] for s in range(n_seg)]
         codes = hp.generate(prompts, n_codes, repetition_penalty=10.0, fixed_length=True)
         t1 = tick()
@@ -277,10 +292,26 @@ def main():
             t_s2 = (time.perf_counter() - tc) * 25
             s2_note = f", s2mel 1 of 25 Euler steps at T={Tref + frames} ({t_s2 / 25:.2f} s/step)"
             log(f"cpu s2mel {t_s2 / 25:.2f} s/step")
-        est = n_seg * (t_prefill + n_codes * t_step + (P + n_codes + 2) * t_lat_row + t_s2 + frames * t_frame)
+        t_cond = 0.0
+        cond_note = ""
+        if use_cond:
+            # same for the conditioning glue: the reference computes it per segment (infer_v2.py:629-635), so does this leg
+            import voice_tts_amd.conditioning as CD
+
+            cpu_cd = CD.Conditioning(CD.make_cond_weights(CD.COND_CFG, seed=1234), CD.COND_CFG, device="cpu")
+            sc = spk_cond_emb.cpu()
+            ls = torch.tensor([sc.shape[-1]])
+            tc = time.perf_counter()
+            with torch.no_grad():
+                cpu_cd.merge_emovec(sc, sc, ls, ls, alpha=1.0)
+                cpu_cd.get_conditioning(sc.transpose(1, 2), ls)
+            t_cond = time.perf_counter() - tc
+            cond_note = f", conditioning encoders on 249 frames ({t_cond:.2f} s per segment)"
+            log(f"cpu conditioning {t_cond:.2f} s")
+        est = n_seg * (t_cond + t_prefill + n_codes * t_step + (P + n_codes + 2) * t_lat_row + t_s2 + frames * t_frame)
         cpu = {"value": round(audio_s / est, 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
                "sample": f"oracle fp32: 1 prefill of {P} rows ({t_prefill:.2f}s), {n_dec} decode steps ({t_step*1e3:.1f} ms/step), "
-                         f"latent pass on {n_lat} codes ({t_lat_row*1e3:.2f} ms/row), BigVGAN {f_s} frames ({t_frame*1e3:.1f} ms/frame){s2_note}; "
+                         f"latent pass on {n_lat} codes ({t_lat_row*1e3:.2f} ms/row), BigVGAN {f_s} frames ({t_frame*1e3:.1f} ms/frame){s2_note}{cond_note}; "
                          f"extrapolated linearly to the full request ({est:.0f}s est.)",
                "rtf": round(est / audio_s, 3)}
 
@@ -291,15 +322,18 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "rtf": round(elapsed / (audio_s * args.steps), 5),
             "config": {
-                "workload": f"1 /tts request per GPU: {n_seg}x{n_tok}-token zh text segments (200-char utterance), greedy fixed-length "
-                            f"decode {n_codes} codes/segment batched B={n_seg}, latent GPT forward, "
+                "workload": f"1 /tts request per GPU: {n_seg}x{n_tok}-token zh text segments (200-char utterance), "
+                            + ("conditioning encoders on 249 prompt frames (conformer + perceiver, PyTorch-ROCm glue, fp32), " if use_cond else "")
+                            + f"greedy fixed-length decode {n_codes} codes/segment batched B={n_seg}, latent GPT forward, "
                             + ("s2mel (length regulator + 25-step CFM/DiT, PyTorch-ROCm glue, fp32, 430-frame prompt), " if use_s2mel else "s2mel skipped (synthetic mel), ")
-                            + f"BigVGAN {frames} frames/segment -> {audio_s:.2f} s audio; prompt feature extraction and conditioning "
-                            f"encoders not built: conds_latent / prompt_condition / ref_mel / style are synthetic HBM-resident inputs",
+                            + f"BigVGAN {frames} frames/segment -> {audio_s:.2f} s audio; prompt feature extraction (w2v-bert, CAM++, semantic "
+                            f"codec, reference mel) not built: spk_cond_emb / prompt_condition / ref_mel / style are synthetic HBM-resident inputs"
+                            + ("" if use_cond else " and so is conds_latent"),
                 "segments": n_seg, "text_tokens_per_segment": n_tok, "codes_per_segment": n_codes, "mel_frames_per_segment": frames,
                 "audio_seconds_per_request": round(audio_s, 3), "parallelism": f"request-per-GPU x{world}, RCCL weight broadcast at load",
                 "gpt_precision": f"{args.dtype} weights+KV, fp32 accumulate", "bigvgan_precision": "fp32 (fp32 MFMA)",
-                "s2mel": "torch fp32 glue in the timed region" if use_s2mel else "excluded",
+                "s2mel": "torch fp32 glue + HIP attention / row kernels in the timed region" if use_s2mel else "excluded",
+                "conditioning": "torch fp32 glue in the timed region (inside gpt_gen)" if use_cond else "excluded",
             },
             "stage_ms_per_step": {k: round(v / args.steps, 2) for k, v in stage_ms.items()},
             "load_s": round(t_load, 1),

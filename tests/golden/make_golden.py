@@ -363,6 +363,58 @@ def gen_s2mel():
          noise=noise, gpt_layer_out=lat, vq_emb=q.vq2emb(codes).transpose(1, 2), cond=cond, dit_one=one, mel=mel[:, :, Tp:], n_steps=3)
 
 
+# ----------------------------------------------------------------------------- N2 (conditioning encoders)
+def gen_conditioning():
+    """Reference ConformerEncoder + PerceiverResampler composed exactly as UnifiedVoice.get_conditioning / get_emovec /
+    merge_emovec compose them (model_v2.py:349-377,513-549,736-747), on a small twin, with our seeded weights loaded."""
+    import torch.nn as nn
+    import voice_tts_amd.conditioning as CD
+    from indextts.gpt.conformer_encoder import ConformerEncoder
+    from indextts.gpt.perceiver import PerceiverResampler
+
+    cfg = CD.tiny_cond_cfg()
+    W = CD.make_cond_weights(cfg, seed=81)
+    cm, em, D = cfg["condition_module"], cfg["emo_condition_module"], cfg["model_dim"]
+    mk_enc = lambda m: ConformerEncoder(input_size=cfg["input_size"], output_size=m["output_size"], linear_units=m["linear_units"],
+                                        attention_heads=m["attention_heads"], num_blocks=m["num_blocks"], input_layer="conv2d2").eval()
+    enc, emo_enc = mk_enc(cm), mk_enc(em)
+    perc = PerceiverResampler(D, dim_context=cm["output_size"], ff_mult=cm["perceiver_mult"], heads=cm["attention_heads"],
+                              num_latents=cfg["cond_num"], dim_head=cfg["perceiver_dim_head"]).eval()
+    emo_perc = PerceiverResampler(cfg["emo_dim"], dim_context=em["output_size"], ff_mult=em["perceiver_mult"], heads=em["attention_heads"],
+                                  num_latents=1, dim_head=cfg["perceiver_dim_head"]).eval()
+    emovec_layer, emo_layer = nn.Linear(cfg["emo_dim"], D), nn.Linear(D, D)
+    used = set()
+    for mod, pre in ((enc, "conditioning_encoder."), (perc, "perceiver_encoder."), (emo_enc, "emo_conditioning_encoder."),
+                     (emo_perc, "emo_perceiver_encoder."), (emovec_layer, "emovec_layer."), (emo_layer, "emo_layer.")):
+        used |= _load_folded_into_reference(mod, W, pre)
+    assert not (set(W) - used), sorted(set(W) - used)[:5]
+    pad_c, pad_e = nn.ConstantPad1d((cfg["cond_num"], 0), True), nn.ConstantPad1d((1, 0), True)
+
+    def get_conditioning(x, lens):  # x [B, idim, T]
+        h, mask = enc(x.transpose(1, 2), lens)
+        return perc(h, pad_c(mask.squeeze(1)))
+
+    def get_emovec(x, lens):  # x [B, T, idim]
+        h, mask = emo_enc(x, lens)
+        v = emo_perc(h, pad_e(mask.squeeze(1))).squeeze(1)
+        return emo_layer(emovec_layer(v))
+
+    g = torch.Generator().manual_seed(82)
+    T = 23
+    spk = torch.randn(2, T, cfg["input_size"], generator=g)
+    emo = torch.randn(2, T - 4, cfg["input_size"], generator=g)
+    full, ragged = torch.tensor([T, T]), torch.tensor([T, T - 6])
+    with torch.inference_mode():
+        enc_full, mask_full = enc(spk, full)
+        enc_rag, mask_rag = enc(spk, ragged)
+        cond_full = get_conditioning(spk.transpose(1, 2), full)
+        cond_rag = get_conditioning(spk.transpose(1, 2), ragged)
+        ev_spk, ev_emo = get_emovec(spk, full), get_emovec(emo, torch.tensor([T - 4, T - 4]))
+        merged = ev_spk + 0.7 * (ev_emo - ev_spk)
+    save("conditioning_tiny.npz", seed=81, spk=spk, emo=emo, lens_ragged=ragged, enc_full=enc_full, enc_ragged=enc_rag, mask_ragged=mask_rag,
+         cond_full=cond_full, cond_ragged=cond_rag, emovec_spk=ev_spk, emovec_emo=ev_emo, merged_alpha07=merged)
+
+
 # ----------------------------------------------------------------------------- G8
 def gen_sampler():
     from transformers.generation.logits_process import (
@@ -388,7 +440,7 @@ def gen_sampler():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["aa", "bigvgan", "gpt", "prod", "sampler", "beam", "s2mel"]
+    which = sys.argv[1:] or ["aa", "bigvgan", "gpt", "prod", "sampler", "beam", "s2mel", "cond"]
     if "aa" in which:
         gen_aa_snake()
     if "bigvgan" in which:
@@ -403,3 +455,5 @@ if __name__ == "__main__":
         gen_beam()
     if "s2mel" in which:
         gen_s2mel()
+    if "cond" in which:
+        gen_conditioning()

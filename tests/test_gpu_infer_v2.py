@@ -120,3 +120,53 @@ def test_missing_glue_is_loud():
         m.infer("spk.wav", "hi", None)
     with pytest.raises(FileNotFoundError):
         IndexTTS2(cfg_path=None, model_dir="/nonexistent", device="cuda:0")
+
+
+def test_infer_with_built_in_conditioning_and_s2mel():
+    """Rows N2 + N1 inside `infer`: the conditioning encoders ride in the GPT state dict, s2mel in `s2mel_state_dict`; the glue
+    then only supplies prompt features and the tokenizer.  The per-request conditioning equals the CPU glue's."""
+    import voice_tts_amd.conditioning as CD
+    import voice_tts_amd.s2mel as S2
+    import voice_tts_amd.weights as WR
+    from indextts.infer_v2 import IndexTTS2
+
+    dev = torch.device("cuda:0")
+    D = 128
+    gcfg = WR.tiny_gpt_cfg(model_dim=D, layers=2, heads=2)
+    bcfg = WR.tiny_bigvgan_cfg(64)
+    ccfg = CD.tiny_cond_cfg(model_dim=D)
+    scfg = S2.tiny_s2mel_cfg(gpt_dim=D)
+    Wg = dict(WR.make_gpt_weights(gcfg, seed=7))
+    Wc = CD.make_cond_weights(ccfg, seed=9)
+    Wg.update(Wc)
+    Ws = S2.make_s2mel_weights(scfg, seed=10)
+
+    class PromptGlue(FakeGlue):
+        def speaker(self, spk_audio_prompt):
+            self.calls["speaker"] += 1
+            g = torch.Generator().manual_seed(21)
+            return dict(spk_cond_emb=torch.randn(1, 19, ccfg["input_size"], generator=g).to(self.dev), style=torch.randn(1, scfg["style_dim"], generator=g).to(self.dev),
+                        prompt_condition=torch.randn(1, 6, scfg["content_dim"], generator=g).to(self.dev), ref_mel=(torch.randn(1, 80, 6, generator=g) * 2 - 4).to(self.dev))
+
+        def emotion(self, emo_audio_prompt):
+            return torch.randn(1, 15, ccfg["input_size"], generator=torch.Generator().manual_seed(22)).to(self.dev)
+
+        def merge_emovec(self, *a):
+            raise AssertionError("the built-in conditioning must be used")
+
+        get_conditioning = s2mel = merge_emovec
+
+    glue = PromptGlue(D, dev)
+    m = IndexTTS2(cfg_path=None, model_dir="/nonexistent", device="cuda:0", glue=glue, gpt_state_dict=Wg, bigvgan_state_dict=WR.make_bigvgan_weights(bcfg, seed=8),
+                  s2mel_state_dict=Ws, gpt_cfg=gcfg, bigvgan_cfg=bcfg, cond_cfg=ccfg, s2mel_cfg=scfg, max_seq=192, max_frames=128)
+    assert m.cond is not None and m.s2mel is not None
+    sr, pcm = m.infer("spk.wav", "abcdefghijklmnop" * 2, None, emo_audio_prompt="emo.wav", emo_alpha=0.7, max_text_tokens_per_segment=20,
+                      num_beams=1, top_k=1, max_mel_tokens=14)
+    assert sr == 22050 and pcm.dtype == np.int16 and pcm.shape[0] == 2 * int(14 * 1.72) * 256 + int(22050 * 0.2)
+    # the hoisted conditioning on the GPU == the CPU glue on the same prompts
+    cpu = CD.Conditioning(Wc, ccfg, "cpu")
+    spk, emo = glue.speaker("x")["spk_cond_emb"].cpu(), glue.emotion("y").cpu()
+    ls, le = torch.tensor([spk.shape[-1]]), torch.tensor([emo.shape[-1]])
+    want = cpu.get_conditioning(spk.transpose(1, 2), ls)[0] + cpu.merge_emovec(spk, emo, ls, le, alpha=0.7)
+    got = m.cond.get_conditioning(spk.to(dev).transpose(1, 2), ls.to(dev))[0] + m.cond.merge_emovec(spk.to(dev), emo.to(dev), ls.to(dev), le.to(dev), alpha=0.7)
+    assert (got.cpu() - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())

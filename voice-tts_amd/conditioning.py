@@ -1,0 +1,238 @@
+"""PyTorch glue for the conditioning encoders -- `north_star` leaves these to PyTorch-ROCm.
+Functional restatement (weights in a flat dict keyed like `UnifiedVoice.state_dict()`) of
+
+  gpt/model_v2.py:513-551,736-747          get_conditioning / get_emo_conditioning / get_emovec / merge_emovec
+  gpt/conformer_encoder.py:56-520           ConformerEncoder(input_layer="conv2d2", rel_pos, no macaron, CNN module k=15)
+  gpt/conformer/subsampling.py:135-186      Conv2dSubsampling2: Conv2d(1, D, 3, stride 2) + ReLU, Linear(D * ((idim-1)//2), D)
+  gpt/conformer/embedding.py:25-141         RelPositionalEncoding: x * sqrt(D), sinusoidal table as pos_emb
+  gpt/conformer/attention.py:26-311         RelPositionMultiHeadedAttention (pos_bias_u / pos_bias_v, rel_shift disabled)
+  gpt/perceiver.py:160-317                  PerceiverResampler (latents attend to [latents; context], GEGLU feed-forward, RMSNorm)
+
+In the reference these run once per text segment although their inputs are per-request constants (infer_v2.py:629-635,
+model_v2.py:684-689); `IndexTTS2.infer` here calls them once per request -- a pure hoist, the values are the same.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+COND_CFG = dict(
+    model_dim=1280, input_size=1024, cond_num=32,
+    condition_module=dict(output_size=512, linear_units=2048, attention_heads=8, num_blocks=6, perceiver_mult=2),
+    emo_condition_module=dict(output_size=512, linear_units=1024, attention_heads=4, num_blocks=4, perceiver_mult=2),
+    cnn_kernel=15, perceiver_depth=2, perceiver_dim_head=64, emo_dim=1024,
+)
+
+
+def tiny_cond_cfg(**kw):
+    c = dict(COND_CFG)
+    c.update(model_dim=48, input_size=21, cond_num=5, emo_dim=40,
+             condition_module=dict(output_size=32, linear_units=64, attention_heads=2, num_blocks=2, perceiver_mult=2),
+             emo_condition_module=dict(output_size=24, linear_units=40, attention_heads=2, num_blocks=2, perceiver_mult=2),
+             perceiver_dim_head=16)
+    c.update(kw)
+    return c
+
+
+def _conformer_shapes(p, idim, m, k):
+    D, U = m["output_size"], m["linear_units"]
+    h = m["attention_heads"]
+    out = [(p + "embed.conv.0.weight", (D, 1, 3, 3)), (p + "embed.conv.0.bias", (D,)),
+           (p + "embed.out.0.weight", (D, D * ((idim - 1) // 2))), (p + "embed.out.0.bias", (D,)),
+           (p + "after_norm.weight", (D,)), (p + "after_norm.bias", (D,))]
+    for i in range(m["num_blocks"]):
+        e = p + f"encoders.{i}."
+        for n in ("linear_q", "linear_k", "linear_v", "linear_out"):
+            out += [(e + f"self_attn.{n}.weight", (D, D)), (e + f"self_attn.{n}.bias", (D,))]
+        out += [(e + "self_attn.linear_pos.weight", (D, D)), (e + "self_attn.pos_bias_u", (h, D // h)), (e + "self_attn.pos_bias_v", (h, D // h)),
+                (e + "feed_forward.w_1.weight", (U, D)), (e + "feed_forward.w_1.bias", (U,)), (e + "feed_forward.w_2.weight", (D, U)), (e + "feed_forward.w_2.bias", (D,)),
+                (e + "conv_module.pointwise_conv1.weight", (2 * D, D, 1)), (e + "conv_module.pointwise_conv1.bias", (2 * D,)),
+                (e + "conv_module.depthwise_conv.weight", (D, 1, k)), (e + "conv_module.depthwise_conv.bias", (D,)),
+                (e + "conv_module.norm.weight", (D,)), (e + "conv_module.norm.bias", (D,)),
+                (e + "conv_module.pointwise_conv2.weight", (D, D, 1)), (e + "conv_module.pointwise_conv2.bias", (D,))]
+        for n in ("norm_ff", "norm_mha", "norm_conv", "norm_final"):
+            out += [(e + n + ".weight", (D,)), (e + n + ".bias", (D,))]
+    return out
+
+
+def _perceiver_shapes(p, dim, dim_context, n_lat, heads, dim_head, mult, depth):
+    inner = heads * dim_head
+    ffi = int(dim * mult * 2 / 3)
+    out = [(p + "latents", (n_lat, dim)), (p + "norm.gamma", (dim,))]
+    if dim_context != dim:
+        out += [(p + "proj_context.weight", (dim, dim_context)), (p + "proj_context.bias", (dim,))]
+    for i in range(depth):
+        out += [(p + f"layers.{i}.0.to_q.weight", (inner, dim)), (p + f"layers.{i}.0.to_kv.weight", (2 * inner, dim)), (p + f"layers.{i}.0.to_out.weight", (dim, inner)),
+                (p + f"layers.{i}.1.0.weight", (2 * ffi, dim)), (p + f"layers.{i}.1.0.bias", (2 * ffi,)),
+                (p + f"layers.{i}.1.2.weight", (dim, ffi)), (p + f"layers.{i}.1.2.bias", (dim,))]
+    return out
+
+
+def cond_shapes(cfg=COND_CFG):
+    """(name, shape) of every conditioning tensor of `UnifiedVoice` (condition_type == "conformer_perceiver")."""
+    D, cm, em = cfg["model_dim"], cfg["condition_module"], cfg["emo_condition_module"]
+    out = _conformer_shapes("conditioning_encoder.", cfg["input_size"], cm, cfg["cnn_kernel"])
+    out += _perceiver_shapes("perceiver_encoder.", D, cm["output_size"], cfg["cond_num"], cm["attention_heads"], cfg["perceiver_dim_head"],
+                             cm["perceiver_mult"], cfg["perceiver_depth"])
+    out += _conformer_shapes("emo_conditioning_encoder.", cfg["input_size"], em, cfg["cnn_kernel"])
+    out += _perceiver_shapes("emo_perceiver_encoder.", cfg["emo_dim"], em["output_size"], 1, em["attention_heads"], cfg["perceiver_dim_head"],
+                             em["perceiver_mult"], cfg["perceiver_depth"])
+    out += [("emovec_layer.weight", (D, cfg["emo_dim"])), ("emovec_layer.bias", (D,)), ("emo_layer.weight", (D, D)), ("emo_layer.bias", (D,))]
+    return out
+
+
+def make_cond_weights(cfg=COND_CFG, seed=1234):
+    """Seeded synthetic weights (no checkpoint exists offline): N(0, 1/fan_in) matrices, small biases, gains near 1."""
+    g = torch.Generator().manual_seed(seed)
+    W = {}
+    for name, shape in cond_shapes(cfg):
+        last = name.rsplit(".", 1)[-1]
+        if last == "gamma" or (last == "weight" and len(shape) == 1):
+            W[name] = 1.0 + 0.1 * torch.randn(*shape, generator=g)
+        elif last == "bias":
+            W[name] = 0.02 * torch.randn(*shape, generator=g)
+        elif last == "latents":
+            W[name] = 0.5 * torch.randn(*shape, generator=g)
+        elif last in ("pos_bias_u", "pos_bias_v"):
+            W[name] = 0.1 * torch.randn(*shape, generator=g)
+        else:
+            fan = 1
+            for d in shape[1:]:
+                fan *= d
+            W[name] = torch.randn(*shape, generator=g) / math.sqrt(fan)
+    return W
+
+
+class Conditioning:
+    def __init__(self, W, cfg=COND_CFG, device="cpu"):
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        self.W = {k: v.to(self.device, torch.float32) for k, v in W.items() if k.split(".")[0] in
+                  ("conditioning_encoder", "perceiver_encoder", "emo_conditioning_encoder", "emo_perceiver_encoder", "emovec_layer", "emo_layer")}
+        self._pe = {}
+
+    # ------------------------------------------------------------------ conformer
+    def _pos_table(self, T, D):
+        key = (D,)
+        if key not in self._pe or self._pe[key].shape[0] < T:
+            n = max(T, 512)
+            pe = torch.zeros(n, D)
+            pos = torch.arange(0, n).unsqueeze(1)
+            div = torch.exp(torch.arange(0, D, 2) * -(math.log(10000.0) / D))
+            pe[:, 0::2] = torch.sin(pos * div)
+            pe[:, 1::2] = torch.cos(pos * div)
+            self._pe[key] = pe.to(self.device)
+        return self._pe[key][:T]
+
+    def _rel_attention(self, x, pos_emb, mask, e, heads):
+        """RelPositionMultiHeadedAttention.forward (attention.py:235-311): scores = ((q+u) k^T + (q+v) p^T) / sqrt(d_k)."""
+        W = self.W
+        B, T, D = x.shape
+        dk = D // heads
+        q = F.linear(x, W[e + "linear_q.weight"], W[e + "linear_q.bias"]).view(B, T, heads, dk)
+        k = F.linear(x, W[e + "linear_k.weight"], W[e + "linear_k.bias"]).view(B, T, heads, dk).transpose(1, 2)
+        v = F.linear(x, W[e + "linear_v.weight"], W[e + "linear_v.bias"]).view(B, T, heads, dk).transpose(1, 2)
+        p = F.linear(pos_emb, W[e + "linear_pos.weight"]).view(1, T, heads, dk).transpose(1, 2)
+        qu = (q + W[e + "pos_bias_u"]).transpose(1, 2)
+        qv = (q + W[e + "pos_bias_v"]).transpose(1, 2)
+        scores = (torch.matmul(qu, k.transpose(-2, -1)) + torch.matmul(qv, p.transpose(-2, -1))) / math.sqrt(dk)
+        if mask is not None:
+            dead = ~mask.unsqueeze(1)  # (B,1,1,T)
+            attn = torch.softmax(scores.masked_fill(dead, -float("inf")), dim=-1).masked_fill(dead, 0.0)
+        else:
+            attn = torch.softmax(scores, dim=-1)
+        y = torch.matmul(attn, v).transpose(1, 2).reshape(B, T, D)
+        return F.linear(y, W[e + "linear_out.weight"], W[e + "linear_out.bias"])
+
+    def _conv_module(self, x, mask, e, k):
+        """ConvolutionModule.forward (conformer_encoder.py:112-160): pw conv -> GLU -> depthwise k -> LayerNorm -> SiLU -> pw conv."""
+        W = self.W
+        x = x.transpose(1, 2)
+        if mask is not None:
+            x = x.masked_fill(~mask, 0.0)
+        x = F.glu(F.conv1d(x, W[e + "pointwise_conv1.weight"], W[e + "pointwise_conv1.bias"]), dim=1)
+        D = x.shape[1]
+        x = F.conv1d(x, W[e + "depthwise_conv.weight"], W[e + "depthwise_conv.bias"], padding=(k - 1) // 2, groups=D)
+        x = F.silu(F.layer_norm(x.transpose(1, 2), (D,), W[e + "norm.weight"], W[e + "norm.bias"], 1e-5)).transpose(1, 2)
+        x = F.conv1d(x, W[e + "pointwise_conv2.weight"], W[e + "pointwise_conv2.bias"])
+        if mask is not None:
+            x = x.masked_fill(~mask, 0.0)
+        return x.transpose(1, 2)
+
+    def conformer(self, xs, lens, prefix, m):
+        """ConformerEncoder.forward: xs [B,T,idim], lens [B] -> (ys [B,T',D], mask [B,1,T']), T' = (T-1)//2."""
+        W = self.W
+        B, T, _ = xs.shape
+        D, heads = m["output_size"], m["attention_heads"]
+        mask = (torch.arange(T, device=xs.device).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(1)  # ~make_pad_mask
+        x = F.relu(F.conv2d(xs.unsqueeze(1), W[prefix + "embed.conv.0.weight"], W[prefix + "embed.conv.0.bias"], stride=2))
+        b, c, t, f = x.shape
+        x = F.linear(x.transpose(1, 2).reshape(b, t, c * f), W[prefix + "embed.out.0.weight"], W[prefix + "embed.out.0.bias"])
+        x = x * math.sqrt(D)
+        pos_emb = self._pos_table(t, D).unsqueeze(0)
+        mask = mask[:, :, 2::2]
+        amask = None if bool(mask.all()) else mask  # one full-length prompt: every masked_fill is a no-op
+        ln = lambda v, n: F.layer_norm(v, (D,), W[n + ".weight"], W[n + ".bias"], 1e-5)
+        for i in range(m["num_blocks"]):
+            e = prefix + f"encoders.{i}."
+            x = x + self._rel_attention(ln(x, e + "norm_mha"), pos_emb, amask, e + "self_attn.", heads)
+            x = x + self._conv_module(ln(x, e + "norm_conv"), amask, e + "conv_module.", self.cfg["cnn_kernel"])
+            h = F.silu(F.linear(ln(x, e + "norm_ff"), W[e + "feed_forward.w_1.weight"], W[e + "feed_forward.w_1.bias"]))
+            x = x + F.linear(h, W[e + "feed_forward.w_2.weight"], W[e + "feed_forward.w_2.bias"])
+            x = ln(x, e + "norm_final")
+        return ln(x, prefix + "after_norm"), mask
+
+    # ------------------------------------------------------------------ perceiver
+    def perceiver(self, x, mask, prefix, heads):
+        """PerceiverResampler.forward (perceiver.py:206-231): x [B,T,C], mask [B, n_lat + T] (True = attend) -> [B,n_lat,dim]."""
+        W, dh = self.W, self.cfg["perceiver_dim_head"]
+        B = x.shape[0]
+        if prefix + "proj_context.weight" in W:
+            x = F.linear(x, W[prefix + "proj_context.weight"], W[prefix + "proj_context.bias"])
+        lat = W[prefix + "latents"].unsqueeze(0).expand(B, -1, -1)
+        dim = lat.shape[-1]
+        n = lat.shape[1]
+        for i in range(self.cfg["perceiver_depth"]):
+            a, f = prefix + f"layers.{i}.0.", prefix + f"layers.{i}.1."
+            ctx = torch.cat((lat, x), dim=-2)  # cross_attn_include_queries
+            q = F.linear(lat, W[a + "to_q.weight"]).view(B, n, heads, dh).transpose(1, 2)
+            kv = F.linear(ctx, W[a + "to_kv.weight"])
+            k, v = kv.chunk(2, dim=-1)
+            k = k.view(B, -1, heads, dh).transpose(1, 2)
+            v = v.view(B, -1, heads, dh).transpose(1, 2)
+            sim = torch.matmul(q, k.transpose(-2, -1)) * (dh ** -0.5)
+            if mask is not None:
+                sim = sim.masked_fill(~mask[:, None, None, :], -torch.finfo(sim.dtype).max)
+            o = torch.matmul(sim.softmax(dim=-1), v).transpose(1, 2).reshape(B, n, heads * dh)
+            lat = F.linear(o, W[a + "to_out.weight"]) + lat
+            u, gate = F.linear(lat, W[f + "0.weight"], W[f + "0.bias"]).chunk(2, dim=-1)  # GEGLU
+            lat = F.linear(F.gelu(gate) * u, W[f + "2.weight"], W[f + "2.bias"]) + lat
+        return F.normalize(lat, dim=-1) * (dim ** 0.5) * W[prefix + "norm.gamma"]  # RMSNorm (perceiver.py:139-158)
+
+    # ------------------------------------------------------------------ UnifiedVoice entry points
+    def get_conditioning(self, spk_cond_emb, lens):
+        """model_v2.py:513-541 (conformer_perceiver): spk_cond_emb [B,1024,T] as the pipeline passes it -> [B,32,model_dim]."""
+        m = self.cfg["condition_module"]
+        x, mask = self.conformer(spk_cond_emb.transpose(1, 2), lens, "conditioning_encoder.", m)
+        cmask = F.pad(mask.squeeze(1), (self.cfg["cond_num"], 0), value=True)
+        return self.perceiver(x, None if bool(cmask.all()) else cmask, "perceiver_encoder.", m["attention_heads"])
+
+    def get_emo_conditioning(self, emo_cond_emb, lens):
+        """model_v2.py:544-549: [B,1024,T] -> [B,emo_dim]."""
+        m = self.cfg["emo_condition_module"]
+        x, mask = self.conformer(emo_cond_emb.transpose(1, 2), lens, "emo_conditioning_encoder.", m)
+        cmask = F.pad(mask.squeeze(1), (1, 0), value=True)
+        return self.perceiver(x, None if bool(cmask.all()) else cmask, "emo_perceiver_encoder.", m["attention_heads"]).squeeze(1)
+
+    def get_emovec(self, emo_cond_emb, lens):
+        """model_v2.py:736-740: [B,T,1024] -> [B,model_dim]."""
+        W = self.W
+        v = self.get_emo_conditioning(emo_cond_emb.transpose(1, 2), lens)
+        v = F.linear(v, W["emovec_layer.weight"], W["emovec_layer.bias"])
+        return F.linear(v, W["emo_layer.weight"], W["emo_layer.bias"])
+
+    def merge_emovec(self, spk_cond_emb, emo_cond_emb, cond_lens, emo_cond_lens, alpha=1.0):
+        """model_v2.py:742-747: base + alpha * (emo - base), both from the emotion encoder."""
+        emo = self.get_emovec(emo_cond_emb, emo_cond_lens)
+        base = self.get_emovec(spk_cond_emb, cond_lens)
+        return base + alpha * (emo - base)

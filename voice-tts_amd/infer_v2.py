@@ -2,14 +2,15 @@
 
 Same constructor and `infer(...)` signature, return values, wav format and log lines as the
 reference (`indextts/infer_v2.py:36-45,438-461,463-783`).  The two hot stages -- the GPT
-(`inference_speech` + latent `forward`) and BigVGAN -- run in libixtts_hip.so.  The stages
-`north_star` leaves to PyTorch glue (audio loading, w2v-bert features, semantic codec,
-CAM++, conformer/perceiver conditioners, s2mel length-regulator + CFM, text front-end) are NOT
-implemented in this repository: they are supplied through a `glue` object (see `Glue`), and
-`infer()` raises a clear `NotImplementedError` when it is missing.  That keeps the
-orchestration (segment loop, generation kwargs, stop-token trimming, PCM conversion, silence
-insertion, streaming) testable today and lets the reference's own modules be plugged in
-unchanged where they are available.
+(`inference_speech` + latent `forward`) and BigVGAN -- run in libixtts_hip.so.  Of the stages
+`north_star` leaves to PyTorch glue this repository builds the conformer/perceiver conditioners
+(`conditioning.py`, used when the GPT checkpoint carries their weights) and the s2mel
+length-regulator + CFM (`s2mel.py`, used when `s2mel_state_dict` is given); audio loading,
+w2v-bert features, the semantic codec, CAM++ and the text front-end are NOT implemented: they are
+supplied through a `glue` object (see `Glue`), and `infer()` raises a clear `NotImplementedError`
+when it is missing.  That keeps the orchestration (segment loop, generation kwargs, stop-token
+trimming, PCM conversion, silence insertion, streaming) testable today and lets the reference's
+own modules be plugged in unchanged where they are available.
 """
 import logging
 import os
@@ -47,22 +48,23 @@ class Glue:
         raise NotImplementedError
 
     def merge_emovec(self, spk_cond_emb, emo_cond_emb, alpha):
-        """UnifiedVoice.merge_emovec -> [1,D] (model_v2.py:742-747)."""
+        """UnifiedVoice.merge_emovec -> [1,D] (model_v2.py:742-747).  Only called when the GPT checkpoint lacks the encoders."""
         raise NotImplementedError
 
     def get_conditioning(self, spk_cond_emb):
-        """UnifiedVoice.get_conditioning -> [32,D] (model_v2.py:514-543,684)."""
+        """UnifiedVoice.get_conditioning -> [32,D] (model_v2.py:514-543,684).  Only called when the GPT checkpoint lacks the encoders."""
         raise NotImplementedError
 
     def s2mel(self, latent, codes, code_lens, speaker):
-        """gpt_layer + vq2emb + length_regulator + cfm.inference -> mel [1,80,F] after the prompt (infer_v2.py:713-731)."""
+        """gpt_layer + vq2emb + length_regulator + cfm.inference -> mel [1,80,F] after the prompt (infer_v2.py:713-731).
+        Only called when no `s2mel_state_dict` was given."""
         raise NotImplementedError
 
 
 class IndexTTS2:
     def __init__(self, cfg_path="models/IndexTTS/config.yaml", model_dir="models/IndexTTS", use_fp16=False, device=None,
                  use_cuda_kernel=None, use_deepspeed=False, *, glue=None, gpt_state_dict=None, bigvgan_state_dict=None,
-                 gpt_cfg=None, bigvgan_cfg=None, max_seq=2048, max_frames=4096):
+                 s2mel_state_dict=None, gpt_cfg=None, bigvgan_cfg=None, cond_cfg=None, s2mel_cfg=None, max_seq=2048, max_frames=4096):
         if device is None:
             if not torch.cuda.is_available():
                 raise RuntimeError("the HIP hot path needs a GPU (no CPU fallback); pass device='cuda:N'")
@@ -106,6 +108,17 @@ class IndexTTS2:
         self.speed_emb = gpt_state_dict["speed_emb.weight"].to(self.device, torch.float32)
         self.gpt_cfg = gcfg
         self.model_dim = D
+        # rows N2 / N1 as PyTorch-ROCm glue, when their weights are there
+        self.cond = None
+        if "conditioning_encoder.embed.conv.0.weight" in gpt_state_dict:
+            from .conditioning import COND_CFG, Conditioning
+
+            self.cond = Conditioning(gpt_state_dict, COND_CFG if cond_cfg is None else cond_cfg, device=self.device)
+        self.s2mel = None
+        if s2mel_state_dict is not None:
+            from .s2mel import S2MEL_CFG, S2Mel
+
+            self.s2mel = S2Mel(s2mel_state_dict, S2MEL_CFG if s2mel_cfg is None else s2mel_cfg, device=self.device)
         # prompt caches (infer_v2.py:190-197)
         self.cache_spk_audio_prompt = None
         self.cache_spk = None
@@ -211,13 +224,25 @@ class IndexTTS2:
         gpt_gen_time = gpt_forward_time = s2mel_time = bigvgan_time = 0.0
         has_warned = False
         silence = None
+        req_emovec = req_cond32 = None
+        if self.cond is not None:
+            # merge_emovec + get_conditioning are functions of the request's prompts only; the reference recomputes them per
+            # segment (infer_v2.py:629-635, model_v2.py:684-689) -- computed once here, same values.  The length arguments
+            # are the reference's: spk_cond_emb.shape[-1] (= 1024, the feature size: no frame is ever masked).
+            m0 = time.perf_counter()
+            sc = spk["spk_cond_emb"].to(self.device, torch.float32)
+            ec = emo_cond_emb.to(self.device, torch.float32)
+            ls, le = torch.tensor([sc.shape[-1]], device=self.device), torch.tensor([ec.shape[-1]], device=self.device)
+            req_emovec = self.cond.merge_emovec(sc, ec, ls, le, alpha=emo_alpha)
+            req_cond32 = self.cond.get_conditioning(sc.transpose(1, 2), ls)[0]
+            gpt_gen_time += time.perf_counter() - m0
         for sent_ids in segments:
             text_tokens = torch.as_tensor(sent_ids, dtype=torch.int32, device=self.device).reshape(-1)
             m0 = time.perf_counter()
-            emovec = glue.merge_emovec(spk["spk_cond_emb"], emo_cond_emb, emo_alpha)
+            emovec = req_emovec if req_emovec is not None else glue.merge_emovec(spk["spk_cond_emb"], emo_cond_emb, emo_alpha)
             if emo_vector is not None:
                 emovec = emovec_mat + (1 - weight_sum) * emovec
-            cond32 = glue.get_conditioning(spk["spk_cond_emb"])
+            cond32 = req_cond32 if req_cond32 is not None else glue.get_conditioning(spk["spk_cond_emb"])
             # inference_speech (model_v2.py:693-734)
             conds_latent = torch.cat((cond32 + emovec.reshape(1, -1), self.speed_emb[1:2], self.speed_emb[0:1]), 0)
             fake, embeds, mask = self._prepare_gpt_inputs(conds_latent, text_tokens)
@@ -252,7 +277,11 @@ class IndexTTS2:
             gpt_forward_time += time.perf_counter() - m0
 
             m0 = time.perf_counter()
-            mel = glue.s2mel(latent, codes, code_lens, spk)
+            if self.s2mel is not None:  # infer_v2.py:713-731
+                mel = self.s2mel(latent, codes, code_lens, spk["prompt_condition"], spk["ref_mel"], spk["style"],
+                                 n_timesteps=25, inference_cfg_rate=0.7)
+            else:
+                mel = glue.s2mel(latent, codes, code_lens, spk)
             torch.cuda.synchronize(self.device)
             s2mel_time += time.perf_counter() - m0
 
