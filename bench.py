@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--codes", type=int, default=1100, help="mel codes per segment (11 per char)")
     ap.add_argument("--segments", type=int, default=2)
     ap.add_argument("--no-s2mel", action="store_true", help="leave the PyTorch-glue s2mel stage out of the timed region (feed synthetic mels)")
+    ap.add_argument("--concurrency", type=int, default=1, help="requests in flight per GPU (config 3 style): their segments share the decode "
+                    "slots through the continuous-batching scheduler (row N3); 1 = BASELINE config[1], the judged line")
     ap.add_argument("--no-cond", action="store_true", help="leave the conditioning encoders out of the timed region (feed a synthetic conds_latent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -83,7 +85,8 @@ def main():
     n_seg, n_tok, n_codes = args.segments, args.tokens, args.codes
     frames = int(n_codes * 1.72)
     P = 34 + n_tok + 2 + 1
-    hp = HotPath(dtype=args.dtype, device=dev, max_batch=max(2, n_seg) if n_seg <= 4 else 4, max_seq=P + n_codes + 64,
+    R = max(1, args.concurrency)
+    hp = HotPath(dtype=args.dtype, device=dev, max_batch=4 if R > 1 else (max(2, n_seg) if n_seg <= 4 else 4), max_seq=P + n_codes + 64,
                  max_frames=frames)
 
     # ---- load: rank 0 builds the (synthetic, seeded) weights, RCCL broadcasts the packed arenas
@@ -143,22 +146,31 @@ def main():
             for s in range(n_seg):
                 conds[s] = cl
         prompts = [hp.prepare_gpt_inputs(conds[s], texts[s])[:2] for s in range(n_seg)]
-        codes = hp.generate(prompts, n_codes, repetition_penalty=10.0, fixed_length=True)
-        t1 = tick()
-        lats = [hp.latent(conds[s], texts[s], codes[s]) for s in range(n_seg)]
-        t2 = tick()
-        if use_s2mel:  # 25 Euler steps x CFG batch 2 over T = 430 + 1892 frames, fp32 (infer_v2.py:713-731)
-            seg_mels = [hp.s2mel(lats[s], codes[s], prompt_condition, ref_mel, style) for s in range(n_seg)]
-            # synthetic weights give arbitrary mel statistics; keep the vocoder input in the log-mel range it is built for
-            seg_mels = [m.clamp(-11.5, 2.0) for m in seg_mels]
+        if R > 1:  # R requests in flight: all their segments go through the continuous-batching scheduler
+            many = hp.generate_many([(e, p, n_codes) for _ in range(R) for (e, p) in prompts], fixed_length=True, repetition_penalty=10.0)
+            codes = many[:n_seg]
         else:
-            seg_mels = mels
-        t2b = tick()
-        wavs = []
-        for s in range(n_seg):
-            w = hp.vocode(seg_mels[s])
-            wavs.append(w.to(torch.int16).cpu())  # wav.cpu() per segment, int16 truncation (infer_v2.py:744,781)
-        t3 = tick()
+            codes = hp.generate(prompts, n_codes, repetition_penalty=10.0, fixed_length=True)
+        t1 = tick()
+        t2 = t2b = t3 = t1
+        for r in range(R):  # the post-decode stages stay per segment (and per request)
+            ta = tick()
+            rc = codes if R == 1 else many[r * n_seg:(r + 1) * n_seg]
+            lats = [hp.latent(conds[s], texts[s], rc[s]) for s in range(n_seg)]
+            tb = tick()
+            if use_s2mel:  # 25 Euler steps x CFG batch 2 over T = 430 + 1892 frames, fp32 (infer_v2.py:713-731)
+                seg_mels = [hp.s2mel(lats[s], rc[s], prompt_condition, ref_mel, style) for s in range(n_seg)]
+                # synthetic weights give arbitrary mel statistics; keep the vocoder input in the log-mel range it is built for
+                seg_mels = [m.clamp(-11.5, 2.0) for m in seg_mels]
+            else:
+                seg_mels = mels
+            tc_ = tick()
+            wavs = []
+            for s in range(n_seg):
+                w = hp.vocode(seg_mels[s])
+                wavs.append(w.to(torch.int16).cpu())  # wav.cpu() per segment, int16 truncation (infer_v2.py:744,781)
+            td = tick()
+            t2, t2b, t3 = t2 + (tb - ta), t2b + (tc_ - ta), t3 + (td - ta)
         if timed:
             stage_ms["gpt_gen"] += (t1 - t0) * 1e3
             stage_ms["gpt_forward"] += (t2 - t1) * 1e3
@@ -190,7 +202,7 @@ def main():
 
     log(f"timed region: {elapsed:.2f}s for {args.steps} steps")
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * audio_s * args.steps / elapsed
+    value = world * R * audio_s * args.steps / elapsed
 
     # ---- roofline of the dominant kernel: the decode-step FC GEMV (largest weight stream per launch),
     # timed live with events on the launch stream, cycling the 24 layers (314 MB bf16 > Infinity Cache)
@@ -320,9 +332,10 @@ def main():
             "metric": "audio_seconds_per_second", "value": round(value, 3), "unit": "audio-s/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "rtf": round(elapsed / (audio_s * args.steps), 5),
+            "rtf": round(elapsed / (R * audio_s * args.steps), 5),
             "config": {
-                "workload": f"1 /tts request per GPU: {n_seg}x{n_tok}-token zh text segments (200-char utterance), "
+                "workload": (f"1 /tts request per GPU: " if R == 1 else f"{R} concurrent /tts requests per GPU (segments share the decode slots, continuous batching B<=4), each ")
+                            + f"{n_seg}x{n_tok}-token zh text segments (200-char utterance), "
                             + ("conditioning encoders on 249 prompt frames (conformer + perceiver, PyTorch-ROCm glue, fp32), " if use_cond else "")
                             + f"greedy fixed-length decode {n_codes} codes/segment batched B={n_seg}, latent GPT forward, "
                             + ("s2mel (length regulator + 25-step CFM/DiT, PyTorch-ROCm glue, fp32, 430-frame prompt), " if use_s2mel else "s2mel skipped (synthetic mel), ")

@@ -1,0 +1,66 @@
+"""Row N3 host logic: the decode scheduler against a scripted engine (no GPU)."""
+import numpy as np
+import torch
+
+from voice_tts_amd.scheduler import DecodeScheduler, Segment
+
+STOP = 99
+
+
+class ScriptedEngine:
+    """Slot b emits script[b][k] at its k-th step after prefill; the script is chosen by the prompt's first element."""
+
+    def __init__(self, scripts, max_batch, max_seq=64):
+        self.scripts, self.max_batch, self.max_seq = scripts, max_batch, max_seq
+        self.seq = [None] * max_batch
+        self.calls = []
+
+    def prefill(self, b, embeds, pad):
+        key = int(embeds[0, 0])
+        self.seq[b] = dict(key=key, out=[], rows=embeds.shape[0] + 1)
+        self.calls.append(("prefill", b, key))
+
+    def decode(self, n_active, n_steps, **kw):
+        assert all(self.seq[b] is not None for b in range(n_active)), "every active slot needs a prompt"
+        self.calls.append(("decode", n_active, n_steps))
+        for b in range(n_active):
+            s = self.seq[b]
+            for _ in range(n_steps):
+                done = STOP in s["out"] and not kw.get("suppress_stop")
+                script = self.scripts.get(s["key"], [])
+                s["out"].append(STOP if done or len(s["out"]) >= len(script) else script[len(s["out"])])
+                s["rows"] += 1
+                assert s["rows"] < self.max_seq, "a slot ran off the end of its cache"
+
+    def read(self, b):
+        out = np.asarray(self.seq[b]["out"], np.int32)
+        return out, bool((out == STOP).any())
+
+
+def _seg(key, max_new, rows=5):
+    e = torch.zeros(rows, 4)
+    e[0, 0] = key
+    return Segment(request=key // 10, index=key % 10, embeds=e, n_left_pad=0, max_new=max_new)
+
+
+def test_continuous_batching_refills_and_trims():
+    scripts = {11: [1, 2, STOP], 12: [3] * 20, 21: [4, 5, 6, 7, STOP], 22: [8, STOP], 31: [9] * 7}
+    eng = ScriptedEngine(scripts, max_batch=2)
+    got = {}
+    sched = DecodeScheduler(eng, max_batch=2, stop_token=STOP, sync_every=4)
+    stats = sched.run([_seg(k, 10) for k in (11, 12, 21, 22, 31)], lambda seg, ids: got.__setitem__((seg.request, seg.index), ids.tolist()))
+    assert got == {(1, 1): [1, 2, STOP], (1, 2): [3] * 10, (2, 1): [4, 5, 6, 7, STOP], (2, 2): [8, STOP], (3, 1): [9] * 7 + [STOP]}
+    assert stats["refills"] == 3 and stats["busy_slot_steps"] <= stats["slot_steps"]
+    # slot 0 was refilled while slot 1 (the 20-token script, cut at max_new=10) kept going
+    assert [c for c in eng.calls if c[0] == "prefill"][:3] == [("prefill", 0, 11), ("prefill", 1, 12), ("prefill", 0, 21)]
+
+
+def test_fixed_length_and_idle_slot_parking():
+    # one long sequence in slot 1 while slot 0 idles after a short one: the idle slot is re-parked before it overruns max_seq
+    scripts = {1: [5, STOP], 2: [7] * 200}
+    eng = ScriptedEngine(scripts, max_batch=2, max_seq=30)
+    got = {}
+    DecodeScheduler(eng, max_batch=2, stop_token=STOP, sync_every=8).run([_seg(1, 4, rows=15), _seg(2, 20)], lambda s, ids: got.__setitem__(s.index, ids.tolist()),
+                                                                          fixed_length=True)
+    assert got[1] == [5, STOP, STOP, STOP] and got[2] == [7] * 20  # fixed length: nothing is trimmed
+    assert any(c[0] == "prefill" and c[2] == 0 for c in eng.calls), "the idle slot was parked on a stub prompt"

@@ -122,6 +122,18 @@ class HotPath:
                 break
         return out
 
+    def generate_many(self, segments, fixed_length=False, repetition_penalty=10.0, sync_every=64):
+        """Row N3: decode any number of segments (of any number of requests) with continuous batching over the engine's
+        slots.  segments: list of (embeds [P-1,D], n_left_pad, max_new).  Returns the id arrays in submission order."""
+        from .scheduler import DecodeScheduler, Segment
+
+        out = [None] * len(segments)
+        sched = DecodeScheduler(self.gpt, self.gpt.max_batch, self.gpt_cfg["stop_mel_token"], sync_every=sync_every)
+        segs = [Segment(0, i, e, p, n) for i, (e, p, n) in enumerate(segments)]
+        self.last_sched_stats = sched.run(segs, lambda seg, ids: out.__setitem__(seg.index, ids), fixed_length=fixed_length,
+                                          repetition_penalty=repetition_penalty)
+        return out
+
     # ------------------------------------------------------------------ G9
     def latent(self, conds_latent, text_ids, codes):
         prefix = self.latent_prefix(conds_latent, text_ids)

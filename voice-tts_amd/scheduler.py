@@ -1,0 +1,86 @@
+"""Cross-segment / cross-request decode batching.
+
+The reference serialises everything behind one lock and decodes one segment at a time (`server.py:25,384`,
+`infer_v2.py:616`).  The decode step here reads the weights once for up to `max_batch` sequences (B=4 costs 1.35x the
+B=2 step, r01), so a worker that owns a GPU keeps its decode slots full: segments of any queued request are prefilled
+into free slots, all slots step together, a finished slot is handed back and refilled while the others keep going
+(continuous batching).  Greedy results do not depend on the company a sequence keeps -- every slot's arithmetic is
+its own, in a fixed order -- which `tests/test_gpu_scheduler.py` checks against one-at-a-time decoding.
+"""
+import collections
+
+import numpy as np
+
+
+class Segment:
+    """One text segment of one request, ready for the decode engine."""
+
+    __slots__ = ("request", "index", "embeds", "n_left_pad", "max_new", "payload")
+
+    def __init__(self, request, index, embeds, n_left_pad, max_new, payload=None):
+        self.request, self.index, self.embeds, self.n_left_pad, self.max_new, self.payload = request, index, embeds, n_left_pad, max_new, payload
+
+
+def live_stub(engine, like):
+    """A 2-row prompt of zeros shaped like `like` [P-1, D] (what an idle slot is parked on)."""
+    return like[:2] * 0
+
+
+class DecodeScheduler:
+    """Keeps the engine's decode slots busy with segments from a queue.
+
+    engine: `GptEngine`-like object with prefill(slot, embeds, n_left_pad), decode(n_active, n_steps, **sampler) and
+    read(slot) -> (ids, finished).  `stop_token` ends a sequence (inclusive) unless `fixed_length`.
+    """
+
+    def __init__(self, engine, max_batch, stop_token, sync_every=64):
+        assert 1 <= max_batch
+        self.engine, self.max_batch, self.stop_token, self.sync_every = engine, max_batch, stop_token, sync_every
+        self.stats = dict(decode_calls=0, slot_steps=0, busy_slot_steps=0, refills=0)
+
+    def run(self, segments, on_done, fixed_length=False, **sampler):
+        """Decode every segment; `on_done(segment, ids)` is called as each finishes (ids: int32 array, stop token included
+        when it was produced).  Order of completion is not the order of submission."""
+        queue = collections.deque(segments)
+        slots = [None] * self.max_batch  # (segment, steps issued so far)
+        length = [0] * self.max_batch    # rows each slot's sequence holds (a freed slot below n_active keeps stepping)
+        max_seq = getattr(self.engine, "max_seq", None)
+        primed = 0                       # slots that have held a sequence at least once (the engine needs a prompt in every active slot)
+        while queue or any(s is not None for s in slots):
+            for b in range(self.max_batch):
+                if slots[b] is None and queue and b <= primed:
+                    seg = queue.popleft()
+                    self.engine.prefill(b, seg.embeds, seg.n_left_pad)
+                    if b < primed:
+                        self.stats["refills"] += 1
+                    primed = max(primed, b + 1)
+                    slots[b] = [seg, 0]
+                    length[b] = int(seg.embeds.shape[0]) + 1
+            live = [b for b in range(self.max_batch) if slots[b] is not None]
+            n_active = max(live) + 1
+            steps = min([self.sync_every] + [slots[b][0].max_new - slots[b][1] for b in live])
+            if max_seq is not None:
+                for b in range(n_active):  # an idle slot under a busy one must not run off the end of its cache: restart it on a stub prompt
+                    if slots[b] is None and length[b] + steps >= max_seq - 2:
+                        self.engine.prefill(b, live_stub(self.engine, slots[live[0]][0].embeds), 0)
+                        length[b] = 3
+            if steps > 0:
+                self.engine.decode(n_active, steps, suppress_stop=fixed_length, **sampler)
+                self.stats["decode_calls"] += 1
+                self.stats["slot_steps"] += n_active * steps
+                self.stats["busy_slot_steps"] += len(live) * steps
+                for b in range(n_active):
+                    length[b] += steps
+            for b in live:
+                seg = slots[b][0]
+                slots[b][1] += steps
+                ids, fin = self.engine.read(b)
+                if fin or slots[b][1] >= seg.max_new:
+                    ids = np.asarray(ids[: seg.max_new])
+                    if not fixed_length:
+                        hit = np.nonzero(ids == self.stop_token)[0]
+                        if hit.size:
+                            ids = ids[: hit[0] + 1]
+                    on_done(seg, ids)
+                    slots[b] = None
+        return self.stats
