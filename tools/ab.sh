@@ -1,2 +1,1 @@
-timeout -k 10 900 python bench.py --concurrency 2 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/bench_c2.json 2> gpurun_out/bench_c2.err; tail -2 gpurun_out/bench_c2.err; cut -c1-330 gpurun_out/bench_c2.json; grep -o "stage_ms_per_step[^}]*}" gpurun_out/bench_c2.json
-timeout -k 10 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/bench_c1.json 2> gpurun_out/bench_c1.err; cut -c1-200 gpurun_out/bench_c1.json; grep -o "stage_ms_per_step[^}]*}" gpurun_out/bench_c1.json
+timeout -k 10 600 python -m pytest tests/test_gpu_s2mel.py -m gpu -x -q > gpurun_out/t.log 2>&1; tail -3 gpurun_out/t.log; timeout -k 10 300 python tools/prof_s2mel.py 25 2>&1 | grep s2mel

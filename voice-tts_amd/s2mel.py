@@ -229,6 +229,9 @@ class S2Mel:
         self.proj_b = torch.cat([W[n + ".project_layer.bias"] for n in names], 0).contiguous()
         mw = W["cfm.estimator.cond_x_merge_linear.weight"]  # input = [x (C) | prompt_x (C) | cond (H) | style]
         self.merge_x, self.merge_rest = mw[:, :C_].contiguous(), mw[:, C_:].contiguous()
+        wn = "cfm.estimator.wavenet."
+        self.wn_taps = [[W[wn + f"in_layers.{i}.conv.conv.weight"][:, :, j].contiguous() for j in range(cfg["wavenet_kernel"])]
+                        for i in range(cfg["wavenet_layers"])]
         sw = W["cfm.estimator.skip_linear.weight"]  # input = [x_res (H) | x (C)]
         self.skipl_res, self.skipl_x = sw[:, :H].contiguous(), sw[:, H:].contiguous()
 
@@ -333,7 +336,15 @@ class S2Mel:
             tot = (k - 1) * d
             right = tot // 2
             xin = _pad_reflect(x, tot - right, right)  # SConv1d non-causal: left = total - total//2 (encodec.py:224-227)
-            xin = F.conv1d(xin, W[p + f"in_layers.{i}.conv.conv.weight"], W[p + f"in_layers.{i}.conv.conv.bias"], dilation=d)
+            if x.is_cuda:
+                # k accumulated GEMMs on shifted views of the padded input (one per tap) instead of im2col + GEMM
+                wk, T_ = self.wn_taps[i], x.shape[-1]
+                acc = W[p + f"in_layers.{i}.conv.conv.bias"][None, :, None].expand(x.shape[0], -1, T_)
+                for j in range(k):
+                    acc = torch.baddbmm(acc, wk[j].expand(x.shape[0], -1, -1), xin[:, :, j * d:j * d + T_])
+                xin = acc
+            else:
+                xin = F.conv1d(xin, W[p + f"in_layers.{i}.conv.conv.weight"], W[p + f"in_layers.{i}.conv.conv.bias"], dilation=d)
             acts = wn_gate(xin, g, i * 2 * Hw, Hw)
             rs = F.conv1d(acts, W[p + f"res_skip_layers.{i}.conv.conv.weight"], W[p + f"res_skip_layers.{i}.conv.conv.bias"])
             if i < nl - 1:
