@@ -15,6 +15,7 @@ Runs on whatever device its tensors live on (GPU in the pipeline; CPU in the par
 explicit argument so CPU/GPU runs can share it.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -207,10 +208,38 @@ def wn_gate(a, g, off, C_):
     return torch.tanh(x[:, :C_]) * torch.sigmoid(x[:, C_:])
 
 
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunable", "gfx950_s2mel.csv")
+
+
+def use_tuned_gemms(path=TUNED_GEMMS):
+    """Library-GEMM selection for the DiT's fp32 GEMMs: PyTorch's TunableOp picks, per (layout, M, N, K), the fastest
+    hipBLASLt / rocBLAS solution from a results file recorded on an MI355X with `tools/tune_gemms.py` (production shapes,
+    T = 430 + 1892: wqkv 79 -> 56 us, [w1; w3] 136 -> 106 us, wo 40 -> 26 us).  Shapes without an entry keep the default
+    heuristic; `IXTTS_TUNE=1` tunes new shapes online (seconds per shape, once).  Returns True when the file was taken."""
+    if not torch.cuda.is_available():
+        return False
+    import torch.cuda.tunable as tn
+
+    tn.enable(True)
+    tn.tuning_enable(os.environ.get("IXTTS_TUNE") == "1")
+    try:
+        import tempfile
+
+        tn.set_filename(os.path.join(tempfile.gettempdir(), "ixtts_tunableop_online.csv"))  # where online tuning (if on) records
+    except Exception:
+        pass
+    try:
+        return bool(os.path.isfile(path) and tn.read_file(path))
+    except Exception:  # a file recorded under other library versions is refused by its validators: default heuristics
+        return False
+
+
 class S2Mel:
     def __init__(self, W, cfg=S2MEL_CFG, device="cpu"):
         self.cfg = dict(cfg)
         self.device = torch.device(device)
+        if self.device.type == "cuda" and os.environ.get("IXTTS_NO_TUNED_GEMMS") != "1":
+            self.tuned_gemms = use_tuned_gemms()
         W = fold_weight_norm(dict(W))
         self.W = {k: v.to(self.device, torch.float32) for k, v in W.items()}
         H = cfg["hidden_dim"]
