@@ -1,1 +1,2 @@
-timeout -k 10 600 python -m pytest tests/test_gpu_s2mel.py -m gpu -x -q > gpurun_out/t.log 2>&1; tail -3 gpurun_out/t.log; timeout -k 10 300 python tools/prof_s2mel.py 25 2>&1 | grep s2mel
+python tools/prof_rows.py 2>&1 | grep prefill
+timeout -k 10 900 python -m pytest tests/test_gpu_gpt.py tests/test_gpu_fullsize.py -m gpu -x -q > gpurun_out/t.log 2>&1; tail -3 gpurun_out/t.log

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void final_norm_rows_kernel(const float* __res
   for (int i = 0; i < PL; ++i) yr[lane + 64 * i] = v[i];
 }
 
-// ---- GEMM: C[T][N] = A[T][K] . Wt[N][K]^T + bias, tile 64 x 128 x 32, 4 waves (2 x 2), wave tile 32 x 64
+// ---- GEMM: C[T][N] = A[T][K] . Wt[N][K]^T + bias
 enum { RE_QKV = 0, RE_RESID = 1, RE_GELU = 2 };
 
 struct GemmArgs {
@@ -101,122 +101,158 @@ struct GemmArgs {
   int T, N, K, pos0, smax, D;
 };
 
-constexpr int GBM = 64, GBN = 128, GBK = 32;
+constexpr int GBN = 128;
 
-template <typename WT, int EPI, typename KVT>
+// Tile BM x 128 x BK, 4 waves as 2 x 2, wave tile (BM/2) x 64.  bf16: BK = 64, both operands staged as bf16 in LDS (the
+// fp32 activations are converted in the staging pass), rows padded to 144 B so the 16-byte fragment reads of 8 consecutive
+// rows fall in 8 different bank groups; fp32: BK = 32, pitch 33.  The global loads of k-tile i+1 are issued before the
+// MFMAs of k-tile i and written to LDS after them (one register set, one LDS buffer, two barriers per k-tile).
+template <typename WT, int EPI, typename KVT, int BM>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   constexpr bool F32 = sizeof(WT) == 4;
-  // LDS tiles; bf16 tiles are stored as 16-bit with an 8-element pad, fp32 with a 1-float pad
-  constexpr int APITCH = F32 ? (GBK + 1) : (GBK + 8) / 2;  // in floats (bf16: 20 floats = 40 bf16)
-  constexpr int WPITCH = APITCH;
-  __shared__ __attribute__((aligned(16))) float As[GBM * APITCH];
-  __shared__ __attribute__((aligned(16))) float Ws[GBN * WPITCH];
+  constexpr int BK = F32 ? 32 : 64;
+  constexpr int MI = BM / 64;                              // 32-row blocks per wave
+  constexpr int PITCH = F32 ? (BK + 1) : (BK + 8) / 2;     // floats per LDS row (bf16: 72 halfs = 36 floats)
+  __shared__ __attribute__((aligned(16))) float As[BM * PITCH];
+  __shared__ __attribute__((aligned(16))) float Ws[GBN * PITCH];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * GBN;
 
-  f32x16 acc[2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.f;
 
-  for (int k0 = 0; k0 < g.K; k0 += GBK) {
-    __syncthreads();
-    // ---- stage A tile [64][32] fp32 (2 float4 per thread)
+  constexpr int NA = BM * BK / 4 / 256;                    // float4 of A per thread per k-tile
+  constexpr int NW = F32 ? GBN * BK / 4 / 256 : GBN * BK / 8 / 256;  // 16-byte pieces of W per thread
+  constexpr int AC = BK / 4;                               // float4 per A row
+  constexpr int WC = F32 ? BK / 4 : BK / 8;                // 16-byte pieces per W row
+  constexpr int PD = 1;  // k-tiles in flight ahead of the MFMAs (register sets); r01: 3 sets measured slower (latent pass 21.4 vs 16.6 ms)
+  float4 aR[PD][NA];
+  uint4 wR[PD][NW];
+  // (loads are unconditional -- rows and k offsets clamped -- so the compiler's vmcnt counting stays exact: a stage is
+  //  written to LDS as soon as ITS loads have landed, with the younger stages still in flight)
+  auto stage_load = [&](float4 (&ar)[NA], uint4 (&wr)[NW], int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int idx = tid + i * 256;
-      const int row = idx >> 3, c4 = idx & 7;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m0 + row < g.T) v = *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + row) * g.K + k0 + c4 * 4);
+      const int row = min(m0 + idx / AC, g.T - 1);  // rows beyond T repeat the last one; their outputs are never stored
+      ar[i] = *reinterpret_cast<const float4*>(g.A + (size_t)row * g.K + k0 + (idx % AC) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int idx = tid + i * 256;
+      const int row = min(n0 + idx / WC, g.N - 1);
+      wr[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(g.wt) + (size_t)row * g.K + k0 + (idx % WC) * (16 / (int)sizeof(WT)));
+    }
+  };
+  auto stage_write = [&](const float4 (&ar)[NA], const uint4 (&wr)[NW]) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / AC, c4 = idx % AC;
       if constexpr (F32) {
-        float* d = As + row * APITCH + c4 * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        float* d = As + row * PITCH + c4 * 4;
+        d[0] = ar[i].x; d[1] = ar[i].y; d[2] = ar[i].z; d[3] = ar[i].w;
       } else {
         uint2 pk;
-        pk.x = pack_bf16x2(v.x, v.y);
-        pk.y = pack_bf16x2(v.z, v.w);
-        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(As) + row * (APITCH * 2) + c4 * 4) = pk;
+        pk.x = pack_bf16x2(ar[i].x, ar[i].y);
+        pk.y = pack_bf16x2(ar[i].z, ar[i].w);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(As) + row * (PITCH * 2) + c4 * 4) = pk;
       }
     }
-    // ---- stage W tile [128][32]
-    if constexpr (F32) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = tid + i * 256;
-        const int row = idx >> 3, c4 = idx & 7;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n0 + row < g.N) v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.wt) + (size_t)(n0 + row) * g.K + k0 + c4 * 4);
-        float* d = Ws + row * WPITCH + c4 * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * 256;
-        const int row = idx >> 2, c8 = idx & 3;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (n0 + row < g.N) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(g.wt) + (size_t)(n0 + row) * g.K + k0 + c8 * 8);
-        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(Ws) + row * (WPITCH * 2) + c8 * 8) = v;
+    for (int i = 0; i < NW; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / WC, c = idx % WC;
+      if constexpr (F32) {
+        float* d = Ws + row * PITCH + c * 4;
+        d[0] = __uint_as_float(wr[i].x); d[1] = __uint_as_float(wr[i].y); d[2] = __uint_as_float(wr[i].z); d[3] = __uint_as_float(wr[i].w);
+      } else {
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(Ws) + row * (PITCH * 2) + c * 8) = wr[i];
       }
     }
-    __syncthreads();
+  };
+
+  const int nkt = g.K / BK;
+#pragma unroll
+  for (int s = 0; s < PD; ++s) stage_load(aR[s], wR[s], min(s, nkt - 1) * BK);
+  for (int kt0 = 0; kt0 < nkt; kt0 += PD) {
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+      if (kt0 + s >= nkt) break;
+      __syncthreads();  // every wave is done with the previous k-tile
+      stage_write(aR[s], wR[s]);
+      __syncthreads();
+      stage_load(aR[s], wR[s], min(kt0 + s + PD, nkt - 1) * BK);
     if constexpr (F32) {
 #pragma unroll
-      for (int kk = 0; kk < GBK; kk += 2) {
-        const float a = As[(wm * 32 + l31) * APITCH + kk + lh];
+      for (int kk = 0; kk < BK; kk += 2) {
+        float a[MI], b[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const float b = Ws[(wn * 64 + j * 32 + l31) * WPITCH + kk + lh];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
-        }
+        for (int mi = 0; mi < MI; ++mi) a[mi] = As[(wm * (BM / 2) + mi * 32 + l31) * PITCH + kk + lh];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = Ws[(wn * 64 + j * 32 + l31) * PITCH + kk + lh];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[j], acc[mi][j], 0, 0, 0);
       }
     } else {
       const unsigned short* A16 = reinterpret_cast<const unsigned short*>(As);
       const unsigned short* W16 = reinterpret_cast<const unsigned short*>(Ws);
 #pragma unroll
-      for (int kk = 0; kk < GBK; kk += 16) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(A16 + (wm * 32 + l31) * (APITCH * 2) + kk + lh * 8);
+      for (int kk = 0; kk < BK; kk += 16) {
+        bf16x8 a[MI], b[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const bf16x8 b = *reinterpret_cast<const bf16x8*>(W16 + (wn * 64 + j * 32 + l31) * (WPITCH * 2) + kk + lh * 8);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-        }
+        for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(A16 + (wm * (BM / 2) + mi * 32 + l31) * (PITCH * 2) + kk + lh * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(W16 + (wn * 64 + j * 32 + l31) * (PITCH * 2) + kk + lh * 8);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[j], acc[mi][j], 0, 0, 0);
       }
+    }
     }
   }
   // ---- epilogue (C layout: col = lane&31 -> n, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> m)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + l31;
-    if (n >= g.N) continue;
-    const float bias = g.bias[n];
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= g.T) continue;
-      const float v = acc[j][r] + bias;
-      if constexpr (EPI == RE_RESID) {
-        float* o = g.out + (size_t)m * g.N + n;
-        *o = *o + v;
-      } else if constexpr (EPI == RE_GELU) {
-        g.out[(size_t)m * g.N + n] = gelu_new_f(v);
-      } else {
-        if (n < g.D) {
-          g.out[(size_t)m * g.D + n] = v;
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + l31;
+      if (n >= g.N) continue;
+      const float bias = g.bias[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= g.T) continue;
+        const float v = acc[mi][j][r] + bias;
+        if constexpr (EPI == RE_RESID) {
+          float* o = g.out + (size_t)m * g.N + n;
+          *o = *o + v;
+        } else if constexpr (EPI == RE_GELU) {
+          g.out[(size_t)m * g.N + n] = gelu_new_f(v);
         } else {
-          const int which = n / g.D;
-          const int c = n - which * g.D;
-          const int hh = c / HD, d = c % HD;
-          KVT* cache = reinterpret_cast<KVT*>(which == 1 ? g.kcache : g.vcache);
-          store_kv(cache + ((size_t)hh * g.smax + g.pos0 + m) * HD + d, v);
+          if (n < g.D) {
+            g.out[(size_t)m * g.D + n] = v;
+          } else {
+            const int which = n / g.D;
+            const int c = n - which * g.D;
+            const int hh = c / HD, d = c % HD;
+            KVT* cache = reinterpret_cast<KVT*>(which == 1 ? g.kcache : g.vcache);
+            store_kv(cache + ((size_t)hh * g.smax + g.pos0 + m) * HD + d, v);
+          }
         }
       }
     }
-  }
 }
 
 // ---- causal attention over rows: grid (H, T); row t attends keys [valid_from, pos0 + t]
@@ -253,8 +289,12 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsArgs a) {
 
 template <typename WT, typename KVT, int EPI>
 static void launch_gemm(const GemmArgs& g, hipStream_t st) {
-  dim3 grid(ceil_div(g.N, GBN), ceil_div(g.T, GBM));
-  hipLaunchKernelGGL((gemm_rows_kernel<WT, EPI, KVT>), grid, dim3(256), 0, st, g);
+  // 128-row tiles once there are enough rows to fill the GPU with them (latent pass), 64-row tiles for prompts
+  if (g.T >= 512) {
+    hipLaunchKernelGGL((gemm_rows_kernel<WT, EPI, KVT, 128>), dim3(ceil_div(g.N, GBN), ceil_div(g.T, 128)), dim3(256), 0, st, g);
+  } else {
+    hipLaunchKernelGGL((gemm_rows_kernel<WT, EPI, KVT, 64>), dim3(ceil_div(g.N, GBN), ceil_div(g.T, 64)), dim3(256), 0, st, g);
+  }
 }
 
 template <typename WT, typename KVT, int D>
