@@ -1,0 +1,113 @@
+"""Outer boundary, HTTP side: the /tts surface of the reference's server.py over a stub model (no GPU)."""
+import io
+import wave
+
+import numpy as np
+import pytest
+from fastapi.testclient import TestClient
+
+from voice_tts_amd import emotion as EM
+from voice_tts_amd.server import create_app, is_hex_string, worker_gpu
+
+
+class StubTTS:
+    device, use_fp16 = "cuda:0", True
+
+    def __init__(self):
+        self.calls = []
+
+    def infer(self, spk_audio_prompt, text, output_path, emo_audio_prompt=None, emo_alpha=1.0, emo_vector=None, verbose=False):
+        self.calls.append(dict(spk=spk_audio_prompt, text=text, emo=emo_audio_prompt, alpha=emo_alpha, vec=emo_vector))
+        if text == "boom":
+            raise RuntimeError("kernel exploded")
+        pcm = (np.arange(22050) % 100).astype("<i2")
+        with wave.open(output_path, "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(22050); f.writeframes(pcm.tobytes())
+        return output_path
+
+
+HEX = "00ff" * 60  # 240 hex chars: long enough to count as audio
+
+
+@pytest.fixture
+def client():
+    stub = StubTTS()
+    with TestClient(create_app(lambda: stub)) as c:
+        yield c, stub
+
+
+def test_status_endpoints(client):
+    c, _ = client
+    assert c.get("/").json() == {"status": "running", "model_loaded": True, "service": "IndexTTS API Server - Stateless", "version": "2.0"}
+    assert c.get("/health").json() == {"status": "healthy", "model_loaded": True, "deepspeed_enabled": False}
+    info = c.get("/debug/worker-info").json()
+    assert set(info) == {"worker_id", "pid", "cuda_visible_devices", "gpu_info", "model_info"}
+    assert info["model_info"] == {"loaded": True, "device": "cuda:0", "use_fp16": True, "use_deepspeed": False}
+
+
+def test_health_is_503_before_the_model_is_loaded():
+    app = create_app(lambda: None)
+    c = TestClient(app)  # no lifespan: nothing loaded
+    assert c.get("/health").status_code == 503
+    assert c.get("/").json()["model_loaded"] is False
+    assert c.post("/tts", json={"text": "hi", "spk_audio": HEX}).status_code == 503
+
+
+def test_tts_round_trip_and_emotion_priorities(client):
+    c, stub = client
+    r = c.post("/tts", json={"text": "hello", "spk_audio": HEX})
+    assert r.status_code == 200
+    body = r.json()
+    assert set(body) == {"audio_hex", "audio_length", "inference_time", "rtf", "text"} and body["text"] == "hello"
+    wav = wave.open(io.BytesIO(bytes.fromhex(body["audio_hex"])))
+    assert (wav.getnchannels(), wav.getsampwidth(), wav.getframerate(), wav.getnframes()) == (1, 2, 22050, 22050)
+    assert body["audio_length"] == pytest.approx(1.0) and body["rtf"] == pytest.approx(body["inference_time"] / 1.0)
+    assert stub.calls[-1] == dict(spk=bytes.fromhex(HEX), text="hello", emo=None, alpha=1.0, vec=None)
+    # emotion label: alpha goes into the vector, the call's emo_alpha is forced to 1.0 (server.py:391)
+    c.post("/tts", json={"text": "a", "spk_audio": HEX, "emotion": "高兴", "emo_alpha": 0.6})
+    assert stub.calls[-1]["vec"] == [0.6, 0, 0, 0, 0, 0, 0, 0] and stub.calls[-1]["alpha"] == 1.0 and stub.calls[-1]["emo"] is None
+    # emotion dict: emo_alpha ignored
+    c.post("/tts", json={"text": "a", "spk_audio": HEX, "emotion": {"happy": 0.7, "生气": 0.3}, "emo_alpha": 0.2})
+    assert stub.calls[-1]["vec"] == [0.7, 0.3, 0, 0, 0, 0, 0, 0]
+    # emo_audio beats emotion and carries emo_alpha (server.py:352-370,391)
+    c.post("/tts", json={"text": "a", "spk_audio": HEX, "emo_audio": "ab" * 80, "emotion": "sad", "emo_alpha": 0.4})
+    assert stub.calls[-1]["emo"] == bytes.fromhex("ab" * 80) and stub.calls[-1]["alpha"] == 0.4 and stub.calls[-1]["vec"] is None
+
+
+def test_tts_errors(client, monkeypatch):
+    c, _ = client
+    assert c.post("/tts", json={"text": "a", "spk_audio": "not audio"}).status_code == 400
+    assert c.post("/tts", json={"text": "a", "spk_audio": "abcd"}).status_code == 400           # hex, but too short to be audio
+    assert c.post("/tts", json={"text": "a", "spk_audio": HEX, "emo_alpha": 1.5}).status_code == 422
+    assert c.post("/tts", json={"text": "a", "spk_audio": HEX, "emotion": {"happy": 2}}).status_code == 422
+    r = c.post("/tts", json={"text": "boom", "spk_audio": HEX})
+    assert r.status_code == 500 and "kernel exploded" in r.json()["detail"]
+
+    import requests
+
+    class Resp:
+        status_code, headers, content = 404, {}, b""
+
+        def raise_for_status(self):
+            raise requests.HTTPError(response=self)
+
+    monkeypatch.setattr(requests, "get", lambda url, timeout: Resp())
+    assert c.post("/tts", json={"text": "a", "spk_audio": "https://example.invalid/x.wav"}).status_code == 404  # upstream status passed through
+
+    def slow(url, timeout):
+        raise requests.Timeout()
+
+    monkeypatch.setattr(requests, "get", slow)
+    assert c.post("/tts", json={"text": "a", "spk_audio": "http://example.invalid/x.wav"}).status_code == 408
+
+
+def test_emotion_known_answers_and_helpers():
+    # the reference's docstring examples (emotion.py:269-273,300-304)
+    assert EM.create_emotion_vector("happy", 0.8) == [0.8, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+    assert EM.create_emotion_vector({"高兴": 0.7, "平静": 0.3}) == [0.7, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.3]
+    assert EM.normalize_emotion_label(" Joyful ") == "happy" and EM.normalize_emotion_label("生气") == "angry"
+    assert EM.normalize_emotion_label("???") == "calm"
+    assert EM.normalize_emotion_dict({"happy": 0.7, "joyful": 0.5})["happy"] == 0.7  # one dimension named twice keeps the larger value
+    assert is_hex_string("ab" * 51) and not is_hex_string("ab" * 50) and not is_hex_string("zz" * 60) and not is_hex_string("abc" * 41)
+    # gunicorn worker -> GPU, round robin over the visible list (gunicorn_config.py:53-54)
+    assert [worker_gpu(a, "0,1,2") for a in (1, 2, 3, 4)] == ["0", "1", "2", "0"] and worker_gpu(1, "") is None

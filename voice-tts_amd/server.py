@@ -1,0 +1,275 @@
+"""The reference's HTTP surface (`server.py`) over this repository's `IndexTTS2` -- SURVEY.md 8(b) "HTTP API".
+
+Same endpoints, models, priorities, error codes and CLI as the reference:
+  POST /tts   TTSRequest{text, spk_audio (URL | hex > 100 chars), emo_audio?, emotion? (str | {str: float in [0,1]}), emo_alpha in [0,1] = 1.0}
+              -> TTSResponse{audio_hex, audio_length, inference_time, rtf, text}                       (server.py:183-235,320-440)
+              emo_audio beats emotion (:352-370); emo_alpha is forced to 1.0 unless emo_audio is given (:391)
+  GET /       {"status","model_loaded","service","version"}                                            (:238-246)
+  GET /health {"status","model_loaded","deepspeed_enabled"}; 503 while the model is not loaded         (:249-259)
+  GET /debug/worker-info  worker id, pid, visible devices, GPU and model info                          (:262-317)
+  errors: 400 unusable audio string, 408 download timeout, upstream HTTP status passed through, 500 inference failure,
+          503 model not loaded                                                                         (:134-148,172-180,337-339,430-440)
+  CLI: --host --port(8020) --workers --reload --log-level; workers > 1 through gunicorn with one GPU per worker (:447-551)
+
+One inference at a time per worker process, as the reference's `inference_lock` (:25,384); `deepspeed_enabled` is always
+False (the HIP decode engine stands in DeepSpeed's seam).  The model is built by `model_factory` in the worker process,
+after the GPU for that worker has been chosen -- nothing touches torch at import time (server.py:17-19).
+"""
+import logging
+import os
+import re
+import tempfile
+import threading
+import time
+import wave
+from contextlib import asynccontextmanager
+from typing import Dict, Optional, Union
+
+from fastapi import FastAPI, HTTPException
+from fastapi.middleware.cors import CORSMiddleware
+from pydantic import BaseModel, Field, field_validator
+
+from .emotion import create_emotion_vector
+
+logger = logging.getLogger("indextts.server")
+
+
+def is_hex_string(s):
+    """Hex-encoded audio: only hex digits, even length, and long enough not to be mistaken for a word (server.py:93-99)."""
+    return bool(s) and bool(re.match(r"^[0-9a-fA-F]+$", s)) and len(s) % 2 == 0 and len(s) > 100
+
+
+def is_url(s):
+    return s.startswith(("http://", "https://", "ftp://"))
+
+
+def download_audio_from_url(url, timeout=30.0):
+    import requests
+
+    try:
+        logger.info(f"Downloading audio from URL: {url}")
+        response = requests.get(url, timeout=timeout)
+        response.raise_for_status()
+        ctype = response.headers.get("content-type", "")
+        if ctype and not any(t in ctype.lower() for t in ("audio", "octet-stream", "wav", "mp3", "mpeg")):
+            logger.warning(f"URL content-type may not be audio: {ctype}")
+        return response.content
+    except requests.Timeout:
+        raise HTTPException(status_code=408, detail=f"Download timeout: {url}")
+    except requests.HTTPError as e:
+        raise HTTPException(status_code=e.response.status_code, detail=f"Failed to download audio from URL: HTTP {e.response.status_code}")
+    except Exception as e:
+        raise HTTPException(status_code=500, detail=f"Error downloading audio from URL: {str(e)}")
+
+
+def get_audio_data(audio_input):
+    if is_url(audio_input):
+        return download_audio_from_url(audio_input)
+    if is_hex_string(audio_input):
+        try:
+            return bytes.fromhex(audio_input)
+        except ValueError as e:
+            raise HTTPException(status_code=400, detail=f"Invalid hex encoded audio data: {str(e)}")
+    raise HTTPException(status_code=400, detail="Invalid audio input format. Must be URL (http://, https://) or hex encoded string")
+
+
+class TTSRequest(BaseModel):
+    text: str = Field(..., description="text to synthesise")
+    spk_audio: str = Field(..., description="speaker reference audio (URL or hex)")
+    emo_audio: Optional[str] = Field(None, description="emotion reference audio (URL or hex); takes priority over `emotion`")
+    emotion: Optional[Union[str, Dict[str, float]]] = Field(None, description="one emotion label, or {label: strength in [0,1]}")
+    emo_alpha: float = Field(default=1.0, description="emotion strength in [0,1]")
+
+    @field_validator("emo_alpha")
+    @classmethod
+    def _alpha(cls, v):
+        if not 0.0 <= v <= 1.0:
+            raise ValueError("emo_alpha must be between 0.0 and 1.0")
+        return v
+
+    @field_validator("emotion")
+    @classmethod
+    def _emotion(cls, v):
+        if v is None or isinstance(v, str):
+            return v
+        if isinstance(v, dict):
+            for key, value in v.items():
+                if not isinstance(key, str):
+                    raise ValueError(f"Emotion dict keys must be strings, got {type(key)}")
+                if not isinstance(value, (int, float)):
+                    raise ValueError(f"Emotion dict values must be numbers, got {type(value)}")
+                if not 0.0 <= value <= 1.0:
+                    raise ValueError(f"Emotion values must be between 0.0 and 1.0, got {value}")
+            return v
+        raise ValueError("emotion must be a string or dict")
+
+
+class TTSResponse(BaseModel):
+    audio_hex: str
+    audio_length: float
+    inference_time: float
+    rtf: float
+    text: str
+
+
+def default_model_factory():
+    """What the reference's lifespan does (server.py:66-72), on the HIP path."""
+    from indextts.infer_v2 import IndexTTS2
+
+    return IndexTTS2(cfg_path="models/IndexTTS/config.yaml", model_dir="models/IndexTTS", use_fp16=True, use_cuda_kernel=True, use_deepspeed=False)
+
+
+def create_app(model_factory=default_model_factory):
+    state = {"model": None}
+    inference_lock = threading.Lock()
+
+    @asynccontextmanager
+    async def lifespan(app):
+        worker_id = os.environ.get("WORKER_ID", "unknown")
+        visible = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "default"))
+        logger.info(f"Worker {worker_id} (PID: {os.getpid()}) starting, GPU: {visible}")
+        try:
+            state["model"] = model_factory()
+            logger.info(f"Model loaded successfully on GPU: {visible}")
+        except Exception as e:
+            logger.error(f"Failed to load model: {e}")
+            raise
+        yield
+        logger.info("Worker process shutting down...")
+
+    app = FastAPI(title="IndexTTS API Server - Stateless", lifespan=lifespan)
+    app.add_middleware(CORSMiddleware, allow_origins=["*"], allow_credentials=True, allow_methods=["*"], allow_headers=["*"])
+    app.state.tts = state
+
+    @app.get("/")
+    def root():
+        return {"status": "running", "model_loaded": state["model"] is not None, "service": "IndexTTS API Server - Stateless", "version": "2.0"}
+
+    @app.get("/health")
+    def health_check():
+        if state["model"] is None:
+            raise HTTPException(status_code=503, detail="Model not loaded")
+        return {"status": "healthy", "model_loaded": True, "deepspeed_enabled": False}
+
+    @app.get("/debug/worker-info")
+    def worker_info():
+        import torch
+
+        gpu = {"cuda_available": torch.cuda.is_available(), "device_count": 0, "current_device": None, "device_name": None, "device_properties": None}
+        if torch.cuda.is_available():
+            gpu["device_count"] = torch.cuda.device_count()
+            try:
+                gpu["current_device"] = torch.cuda.current_device()
+                gpu["device_name"] = torch.cuda.get_device_name(0)
+                p = torch.cuda.get_device_properties(0)
+                gpu["device_properties"] = {"name": p.name, "total_memory": f"{p.total_memory / 1024**3:.2f} GB", "major": p.major, "minor": p.minor}
+            except Exception as e:
+                gpu["error"] = str(e)
+        m = state["model"]
+        return {"worker_id": os.environ.get("WORKER_ID", "unknown"), "pid": os.getpid(),
+                "cuda_visible_devices": os.environ.get("CUDA_VISIBLE_DEVICES", "not set"), "gpu_info": gpu,
+                "model_info": {"loaded": m is not None, "device": str(m.device) if m else "not loaded", "use_fp16": m.use_fp16 if m else None,
+                               "use_deepspeed": False}}
+
+    @app.post("/tts", response_model=TTSResponse)
+    def text_to_speech(request: TTSRequest):
+        model = state["model"]
+        if model is None:
+            raise HTTPException(status_code=503, detail="Model not loaded")
+        output_path = None
+        try:
+            logger.info(f"Processing TTS request: text='{request.text[:50]}...'")
+            spk_audio_data = get_audio_data(request.spk_audio)
+            emo_audio_data = emo_vector = None
+            if request.emo_audio:
+                emo_audio_data = get_audio_data(request.emo_audio)
+            elif request.emotion:
+                if isinstance(request.emotion, str):
+                    emo_vector = create_emotion_vector(request.emotion, request.emo_alpha)
+                else:
+                    emo_vector = create_emotion_vector(request.emotion)
+            with tempfile.NamedTemporaryFile(suffix=".wav", delete=False) as tmp:
+                output_path = tmp.name
+            start = time.time()
+            with inference_lock:  # one inference at a time per worker (server.py:25,384)
+                result_path = model.infer(spk_audio_prompt=spk_audio_data, text=request.text, output_path=output_path,
+                                          emo_audio_prompt=emo_audio_data if emo_audio_data else None,
+                                          emo_alpha=request.emo_alpha if emo_audio_data else 1.0, emo_vector=emo_vector, verbose=False)
+            inference_time = time.time() - start
+            with open(result_path, "rb") as f:
+                audio_hex = f.read().hex()
+            with wave.open(result_path, "rb") as w:
+                audio_length = w.getnframes() / float(w.getframerate())
+            rtf = inference_time / audio_length if audio_length > 0 else 0.0
+            os.remove(output_path)
+            logger.info(f"TTS completed: audio_length={audio_length:.2f}s, inference_time={inference_time:.2f}s, rtf={rtf:.4f}, size={len(audio_hex)//2} bytes")
+            return TTSResponse(audio_hex=audio_hex, audio_length=audio_length, inference_time=inference_time, rtf=rtf, text=request.text)
+        except HTTPException:
+            raise
+        except Exception as e:
+            logger.error(f"TTS inference failed: {str(e)}")
+            try:
+                if output_path and os.path.exists(output_path):
+                    os.remove(output_path)
+            except Exception:
+                pass
+            raise HTTPException(status_code=500, detail=f"TTS inference failed: {str(e)}")
+
+    return app
+
+
+def worker_gpu(worker_age, visible):
+    """GPU of the worker gunicorn forked `worker_age`-th (1-based): round-robin over the visible list (gunicorn_config.py:43-60)."""
+    gpus = [g.strip() for g in visible.split(",") if g.strip()] if visible else []
+    return gpus[(worker_age - 1) % len(gpus)] if gpus else None
+
+
+def post_fork(server, worker):
+    """gunicorn hook: pin the freshly forked worker to its GPU before anything imports torch (gunicorn_config.py:43-60).
+    On ROCm the runtime honours HIP_VISIBLE_DEVICES; CUDA_VISIBLE_DEVICES is set too, as the reference does."""
+    visible = os.environ.get("CUDA_VISIBLE_DEVICES") or os.environ.get("HIP_VISIBLE_DEVICES") or ""
+    gpu = worker_gpu(worker.age, visible)
+    os.environ["WORKER_ID"] = str(worker.age)
+    if gpu is not None:
+        os.environ["CUDA_VISIBLE_DEVICES"] = gpu
+        os.environ["HIP_VISIBLE_DEVICES"] = gpu
+
+
+def main(argv=None):
+    import argparse
+
+    ap = argparse.ArgumentParser(description="IndexTTS API Server - Stateless", formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    ap.add_argument("--host", type=str, default="0.0.0.0", help="Host to bind the server to")
+    ap.add_argument("--port", type=int, default=8020, help="Port to bind the server to")
+    ap.add_argument("--workers", type=int, default=1, help="Number of worker processes")
+    ap.add_argument("--reload", action="store_true", help="Enable auto-reload for development")
+    ap.add_argument("--log-level", type=str, default="info", choices=["critical", "error", "warning", "info", "debug", "trace"], help="Log level")
+    args = ap.parse_args(argv)
+    app = create_app()
+    if args.workers > 1:
+        try:
+            from gunicorn.app.base import BaseApplication
+        except ImportError:
+            logger.error("Gunicorn is not installed. Please install it with: pip install gunicorn")
+            logger.error("Or use single worker mode: python server.py --workers 1")
+            raise
+
+        class Standalone(BaseApplication):
+            def load_config(self):
+                for k, v in {"bind": f"{args.host}:{args.port}", "workers": args.workers, "worker_class": "uvicorn.workers.UvicornWorker",
+                             "worker_connections": 1, "threads": 1, "timeout": 300, "keepalive": 5, "loglevel": args.log_level,
+                             "accesslog": "-", "errorlog": "-", "preload_app": False, "post_fork": post_fork}.items():
+                    self.cfg.set(k, v)
+
+            def load(self):
+                return app
+
+        Standalone().run()
+    else:
+        import uvicorn
+
+        uvicorn.run(app, host=args.host, port=args.port, reload=args.reload, log_level=args.log_level)
+
+
+if __name__ == "__main__":
+    main()
