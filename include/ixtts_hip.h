@@ -57,7 +57,7 @@ int ixtts_aa_snake_f32(const float* x_dev, float* y_dev, const float* up12_dev, 
  * q, k, v, out: fp32, element (b, t, h, d) at base[b*stride_b + t*stride_t + h*stride_h + d] (d contiguous,
  * head_dim 64, strides in floats and multiples of 4); out = softmax(scale * q k^T) v per (b, h).
  * workspace_dev (optional, ixtts_attn_full_workspace_bytes(B,H,T) bytes of scratch owned by the caller): lets the kernel
- * split the key range over three workgroups per query block when the un-split grid cannot fill the GPU, plus a merge pass.
+ * split the key range over four workgroups per query block when the un-split grid cannot fill the GPU, plus a merge pass.
  */
 size_t ixtts_attn_full_workspace_bytes(int B, int H, int T);
 int ixtts_attn_full_f32(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, int B, int H, int T,

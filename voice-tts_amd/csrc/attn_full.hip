@@ -10,7 +10,7 @@
 //   O^T += V^T P^T  sums over keys; the MFMA B operand of k-step r is B[k = l>>5][j = l&31] = P^T[key pair of r][query]
 //                 -- exactly that accumulator register.  The A operand V^T[d][key] is read from the V tile in LDS.
 // Every lane owns ONE query column: the online-softmax max/sum/rescale are per-lane scalars (+ one exchange with
-// lane^32, which holds the other half of the keys).  One workgroup = 2 waves = 64 queries; K/V tiles of 64 keys in LDS.
+// lane^32, which holds the other half of the keys).  One workgroup = 4 waves = 128 queries; K/V tiles of 64 keys in LDS.
 //
 // Roofline: 4*T^2*d flops per head (fp32 MFMA peak 157.3 TFLOP/s); K/V re-read T/64 times from L2 (1.2 MB per head).
 #include "common.h"
@@ -22,8 +22,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int AF_D = 64;        // head dim
 constexpr int AF_KT = 64;       // keys per tile
 constexpr int AF_QW = 32;       // queries per wave
-constexpr int AF_WAVES = 2;
-constexpr int AF_KSPLIT = 3;   // key-range splits when the grid is too small (see attn_full_f32_kernel)
+constexpr int AF_WAVES = 4;
+constexpr int AF_KSPLIT = 4;   // key-range splits when the grid is too small (see attn_full_f32_kernel)
 // K tile pitch (floats): rows stay 16-byte aligned (ds_write_b128 / ds_read_b128) and 8 consecutive keys start 17
 // granules apart -> the 8 lanes a b128 read serves per cycle hit 8 different granules mod 8: conflict-free
 constexpr int AF_KP = AF_D + 4;
@@ -84,9 +84,10 @@ __global__ __launch_bounds__(AF_WAVES * 64) void attn_full_f32_kernel(AttnFullAr
   const int t_hi = KSPLIT > 1 ? min(a.T, t_lo + tiles_per * AF_KT) : a.T;
   for (int t0 = t_lo; t0 < t_hi; t0 += AF_KT) {
     __syncthreads();
-    // stage K and V tiles (64 keys x 64 dims): each thread moves 8 float4 of each.  (Measured r01: issuing these loads one
-    // tile ahead and holding them in registers across the MFMAs is slower, 442 vs 362 us -- 64 more live VGPRs; 4-wave
-    // workgroups halve the staging per flop but leave 304 workgroups for 256 CUs, 404 us.)
+    // stage K and V tiles (64 keys x 64 dims): each thread moves 4 float4 of each.  (Measured r01: issuing these loads one
+    // tile ahead and holding them in registers across the MFMAs is slower, 442 vs 362 us with 2-wave workgroups -- 64 more
+    // live VGPRs.  4-wave workgroups halve the staging per flop; un-split they leave 304 workgroups for 256 CUs (404 us),
+    // with the key range split 4 ways they win: 247 us, MFMA busy 64 %.)
 #pragma unroll
     for (int i = 0; i < (AF_KT * AF_D / 4) / (AF_WAVES * 64); ++i) {
       const int idx = threadIdx.x + i * (AF_WAVES * 64);
