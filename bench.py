@@ -258,6 +258,32 @@ def main():
                             "frac": round(step_bytes / step_us / 1e3 / 8000.0, 4), "kernels_per_step": 5 * L + 2},
         }
 
+    # ---- the other stages against their rooflines (fp32 MFMA peak 157.3 TFLOP/s): BigVGAN from its timed stage, the DiT
+    # attention kernel timed live with events on the launch stream (report the binding fraction per family)
+    stage_roof = None
+    if rank == 0 and not args.no_roofline:
+        PEAK_F32 = 157.3
+        bv_tf = hp.bigvgan.flops(1, frames) * n_seg * R / (stage_ms["bigvgan"] / args.steps * 1e-3) / 1e12
+        stage_roof = {"bigvgan": {"bound": "mfma", "achieved": round(bv_tf, 1), "peak": PEAK_F32, "unit": "TFLOP/s", "frac": round(bv_tf / PEAK_F32, 3),
+                                  "flops_per_segment": hp.bigvgan.flops(1, frames)}}
+        if use_s2mel:
+            from voice_tts_amd.s2mel import attn_full
+
+            Ta = Tref + frames
+            qkv = torch.randn(2, Ta, 3, 8, 64, device=dev)
+            for _ in range(3):
+                attn_full(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                attn_full(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])
+            e1.record()
+            torch.cuda.synchronize()
+            us_a = e0.elapsed_time(e1) * 1e3 / 20
+            fl = 4.0 * 2 * 8 * Ta * Ta * 64
+            stage_roof["s2mel_attention"] = {"bound": "mfma", "kernel": "attn_full_f32_kernel + merge (B=2, H=8, T=%d)" % Ta, "achieved": round(fl / us_a / 1e6, 1),
+                                             "peak": PEAK_F32, "unit": "TFLOP/s", "frac": round(fl / us_a / 1e6 / PEAK_F32, 3), "us_per_call": round(us_a, 1)}
+
     # ---- CPU baseline: the oracle (port of the reference's CPU path) on a bounded sample
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -351,6 +377,7 @@ def main():
             "stage_ms_per_step": {k: round(v / args.steps, 2) for k, v in stage_ms.items()},
             "load_s": round(t_load, 1),
             "roofline": roofline,
+            "stage_rooflines": stage_roof,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

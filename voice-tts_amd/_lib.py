@@ -93,6 +93,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its bundled HIP runtime must be the one this process initialises.  Loading libixtts_hip.so before torch
+    # pulls in /opt/rocm's libamdhip64 as a second runtime, and device memory calls through it then fail with
+    # "no ROCm-capable device is detected" (seen when build() ran before smoke() in one process).
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise IxttsError(
             f"{LIB_PATH} not found: build it with `python -m voice_tts_amd.build` "

@@ -319,7 +319,7 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   h->stage_floats = stage_off;
 
   auto fail = [&](const char* what) {
-    set_error("gpt_create: allocation failed (%s)", what);
+    set_error("gpt_create: allocation failed (%s): %s", what, hipGetErrorString(hipGetLastError()));
     ixtts_gpt_destroy(h);
     return IXTTS_ERR_NOMEM;
   };
