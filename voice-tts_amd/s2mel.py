@@ -335,22 +335,24 @@ class S2Mel:
         W, cfg = self.W, self.cfg
         B, T, H = x.shape
         L = cfg["depth"]
-        wb_all = F.linear(c, self.proj_w, self.proj_b).view(B, 2 * L + 1, 2 * H)  # (weight | bias) of every AdaLN
+        # (weight | bias) of every AdaLN, one contiguous [B, 2H] slab per norm
+        wb_all = F.linear(c, self.proj_w, self.proj_b).view(B, 2 * L + 1, 2 * H).transpose(0, 1).contiguous()
         x = x.reshape(B * T, H)
         skips = []
         for i in range(L):
             p = f"cfm.estimator.transformer.layers.{i}."
             if i > L // 2:
                 wa, wb_ = self.skip_w[i]
-                x = torch.addmm(F.linear(skips.pop(), wb_, W[p + "skip_in_linear.bias"]), x, wa.t())
-            a = adaln_rmsnorm(x.view(B, T, H), wb_all[:, 2 * i], W[p + "attention_norm.norm.weight"])
+                x = F.linear(skips.pop(), wb_, W[p + "skip_in_linear.bias"]).addmm_(x, wa.t())
+            a = adaln_rmsnorm(x.view(B, T, H), wb_all[2 * i], W[p + "attention_norm.norm.weight"])
             y = self._attention(F.linear(a.view(B * T, H), W[p + "attention.wqkv.weight"]), B, T, mask)
-            h = torch.addmm(x, y, W[p + "attention.wo.weight"].t())
-            f = adaln_rmsnorm(h.view(B, T, H), wb_all[:, 2 * i + 1], W[p + "ffn_norm.norm.weight"])
-            x = torch.addmm(h, swiglu(F.linear(f.view(B * T, H), self.w13[i])), W[p + "feed_forward.w2.weight"].t())
+            # residuals accumulate in place where the input is private (layer inputs 1..L/2 are also the saved U-ViT skips)
+            h = torch.addmm(x, y, W[p + "attention.wo.weight"].t()) if 0 < i <= L // 2 else x.addmm_(y, W[p + "attention.wo.weight"].t())
+            f = adaln_rmsnorm(h.view(B, T, H), wb_all[2 * i + 1], W[p + "ffn_norm.norm.weight"])
+            x = h.addmm_(swiglu(F.linear(f.view(B * T, H), self.w13[i])), W[p + "feed_forward.w2.weight"].t())
             if i < L // 2:
                 skips.append(x)
-        return adaln_rmsnorm(x.view(B, T, H), wb_all[:, 2 * L], W["cfm.estimator.transformer.norm.norm.weight"])
+        return adaln_rmsnorm(x.view(B, T, H), wb_all[2 * L], W["cfm.estimator.transformer.norm.norm.weight"])
 
     def _wavenet(self, x, x_mask, g, full):
         """WN.forward: reflect-padded dilated convs, tanh*sigmoid gate, residual/skip split (wavenet.py:142-167).
@@ -369,8 +371,9 @@ class S2Mel:
                 # k accumulated GEMMs on shifted views of the padded input (one per tap) instead of im2col + GEMM
                 wk, T_ = self.wn_taps[i], x.shape[-1]
                 acc = W[p + f"in_layers.{i}.conv.conv.bias"][None, :, None].expand(x.shape[0], -1, T_)
-                for j in range(k):
-                    acc = torch.baddbmm(acc, wk[j].expand(x.shape[0], -1, -1), xin[:, :, j * d:j * d + T_])
+                for j in range(k):  # the first tap materialises bias + W_0 x, the others accumulate in place (no copies)
+                    wj, xj = wk[j].expand(x.shape[0], -1, -1), xin[:, :, j * d:j * d + T_]
+                    acc = torch.baddbmm(acc, wj, xj) if j == 0 else acc.baddbmm_(wj, xj)
                 xin = acc
             else:
                 xin = F.conv1d(xin, W[p + f"in_layers.{i}.conv.conv.weight"], W[p + f"in_layers.{i}.conv.conv.bias"], dilation=d)
