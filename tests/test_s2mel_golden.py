@@ -62,3 +62,18 @@ def test_weight_norm_checkpoint_spelling_loads(golden):
     m2 = S2.S2Mel(sd, cfg)
     for k in W:
         assert torch.allclose(m2.W[k], m.W[k], atol=1e-6), k
+
+
+def test_wavenet_gemm_form_equals_the_conv_form():
+    """The pipeline's WaveNet (accumulating GEMMs, residual biases carried into the next conv's bias, skip biases added once)
+    is the reference form re-associated: same values up to fp32 rounding."""
+    import voice_tts_amd.s2mel as S2
+
+    cfg = S2.tiny_s2mel_cfg()
+    m = S2.S2Mel(S2.make_s2mel_weights(cfg, seed=13), cfg, "cpu")
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(2, cfg["wavenet_hidden"], 37, generator=g)
+    t2 = torch.randn(2, cfg["wavenet_hidden"], generator=g)
+    want = m._wavenet(x.clone(), torch.ones(2, 1, 37), t2, True)
+    got = m._wavenet_gemm(x.clone(), t2) + m.wn_out_bias[None, :, None]
+    assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())

@@ -261,6 +261,25 @@ class S2Mel:
         wn = "cfm.estimator.wavenet."
         self.wn_taps = [[W[wn + f"in_layers.{i}.conv.conv.weight"][:, :, j].contiguous() for j in range(cfg["wavenet_kernel"])]
                         for i in range(cfg["wavenet_layers"])]
+        # WaveNet with the residual / skip 1x1 convs as in-place accumulating GEMMs: their biases are constants per channel, so
+        # the residual ones are carried forward into the next layer's conv bias (a reflect-padded constant stays a constant:
+        # conv(x + c) = conv(x) + (sum of taps) c) and the skip ones are added once at the end
+        nl, Hw = cfg["wavenet_layers"], cfg["wavenet_hidden"]
+        self.wn_r1, self.wn_r2, self.wn_bin = [], [], []
+        carry = torch.zeros(Hw, device=self.device)
+        self.wn_out_bias = torch.zeros(Hw, device=self.device)
+        for i in range(nl):
+            rw, rb = W[wn + f"res_skip_layers.{i}.conv.conv.weight"][:, :, 0], W[wn + f"res_skip_layers.{i}.conv.conv.bias"]
+            self.wn_bin.append(W[wn + f"in_layers.{i}.conv.conv.bias"] + sum(self.wn_taps[i]) @ carry)
+            if i < nl - 1:
+                self.wn_r1.append(rw[:Hw].contiguous())
+                self.wn_r2.append(rw[Hw:].contiguous())
+                carry = carry + rb[:Hw]
+                self.wn_out_bias = self.wn_out_bias + rb[Hw:]
+            else:
+                self.wn_r1.append(None)
+                self.wn_r2.append(rw.contiguous())
+                self.wn_out_bias = self.wn_out_bias + rb
         sw = W["cfm.estimator.skip_linear.weight"]  # input = [x_res (H) | x (C)]
         self.skipl_res, self.skipl_x = sw[:, :H].contiguous(), sw[:, H:].contiguous()
 
@@ -388,6 +407,32 @@ class S2Mel:
                 out = rs if out is None else out + rs
         return out if full else out * x_mask
 
+    def _wavenet_gemm(self, x, g):
+        """The same network for the pipeline's case (GPU, every sequence spans T): every conv is an accumulating batched GEMM,
+        no element-wise adds in between (see __init__); returns the skip sum WITHOUT `wn_out_bias` (the caller's linear adds it)."""
+        W, cfg = self.W, self.cfg
+        Hw, nl, k = cfg["wavenet_hidden"], cfg["wavenet_layers"], cfg["wavenet_kernel"]
+        B, _, T_ = x.shape
+        p = "cfm.estimator.wavenet."
+        g = F.linear(g, W[p + "cond_layer.conv.conv.weight"][:, :, 0], W[p + "cond_layer.conv.conv.bias"])
+        x = x.contiguous()
+        out = None
+        for i in range(nl):
+            d = cfg["wavenet_dilation_rate"] ** i
+            tot = (k - 1) * d
+            right = tot // 2
+            xin = _pad_reflect(x, tot - right, right)
+            acc = self.wn_bin[i][None, :, None].expand(B, -1, T_)
+            for j in range(k):
+                wj, xj = self.wn_taps[i][j].expand(B, -1, -1), xin[:, :, j * d:j * d + T_]
+                acc = torch.baddbmm(acc, wj, xj) if j == 0 else acc.baddbmm_(wj, xj)
+            acts = wn_gate(acc, g, i * 2 * Hw, Hw)
+            if i < nl - 1:
+                x = x.baddbmm_(self.wn_r1[i].expand(B, -1, -1), acts)
+            r2 = self.wn_r2[i].expand(B, -1, -1)
+            out = torch.bmm(r2, acts) if out is None else out.baddbmm_(r2, acts)
+        return out
+
     # ------------------------------------------------------------------ DiT + CFM
     def dit_prepare(self, prompt_x, x_lens, style, cond):
         """Everything of DiT.forward that does not depend on (x, t): computed once per CFM solve instead of once per
@@ -422,7 +467,10 @@ class S2Mel:
         x_res = F.linear(x_res, self.skipl_res, W[e + "skip_linear.bias"]) + F.linear(xt, self.skipl_x)
         h = _lin(x_res, W, e + "conv1").transpose(1, 2)
         t2 = self._t_embed(t, e + "t_embedder2")
-        h = self._wavenet(h, ctx["x_mask"], t2, ctx["full"]).transpose(1, 2) + _lin(x_res, W, e + "res_projection")
+        if h.is_cuda and ctx["full"] and T > 2 * self.cfg["wavenet_kernel"] * self.cfg["wavenet_dilation_rate"] ** (self.cfg["wavenet_layers"] - 1):
+            h = self._wavenet_gemm(h, t2).transpose(1, 2) + F.linear(x_res, W[e + "res_projection.weight"], W[e + "res_projection.bias"] + self.wn_out_bias)
+        else:
+            h = self._wavenet(h, ctx["x_mask"], t2, ctx["full"]).transpose(1, 2) + _lin(x_res, W, e + "res_projection")
         ss = _lin(F.silu(t1), W, e + "final_layer.adaLN_modulation.1")
         h = ln_modulate(h, ss)
         h = _lin(h, W, e + "final_layer.linear").transpose(1, 2)
