@@ -929,10 +929,27 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerState s) {
   __shared__ int cand_n;
 
   const int slot = s.slot0 + blockIdx.x;
-  const ixtts_sampler_cfg cfg = *s.cfg;
-  const float theta = cfg.repetition_penalty;
+  // every load whose address is known at entry goes out first, unconditionally (clamped): logits, history bitmap, sampler
+  // configuration, the slot's counters -- one memory round trip instead of a chain of dependent ones
   const float* lg = s.logits + (size_t)slot * s.V;
   const uint8_t* seen = s.seen + (size_t)slot * s.V;
+  float raw[SAMP_PT];
+  uint8_t sn[SAMP_PT];
+#pragma unroll
+  for (int i = 0; i < SAMP_PT; ++i) {
+    const int v = min((int)threadIdx.x + i * 1024, s.V - 1);
+    raw[i] = lg[v];
+    sn[i] = seen[v];
+  }
+  const ixtts_sampler_cfg cfg = *s.cfg;
+  const int st_finished = s.finished[slot], st_forced = s.forced[slot], st_gen = s.gen_count[slot], st_prompt = s.prompt_len[slot];
+  __builtin_amdgcn_sched_barrier(0);
+  // the positional row of the token about to be chosen is known already (k = gen_count + 1 -> row k + 1)
+  const float* pe = s.mel_pos + (size_t)min(st_gen + 2, s.n_pos - 1) * s.D;
+  float pe0 = 0.f, pe1 = 0.f;
+  if ((int)threadIdx.x < s.D) pe0 = pe[threadIdx.x];
+  if ((int)threadIdx.x + 1024 < s.D) pe1 = pe[threadIdx.x + 1024];
+  const float theta = cfg.repetition_penalty;
   const bool sampling = cfg.do_sample != 0;
   const float inv_t = (sampling && cfg.temperature > 0.f) ? 1.0f / cfg.temperature : 1.0f;
 
@@ -944,10 +961,10 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerState s) {
     const int v = threadIdx.x + i * 1024;
     float x = -INFINITY;
     if (v < s.V) {
-      x = lg[v];
+      x = raw[i];
       if (cfg.suppress_stop && v == s.stop) x = -INFINITY;
-      if (seen[v] && theta != 1.0f) x = (x < 0.f) ? x * theta : x / theta;  // RepetitionPenaltyLogitsProcessor
-      if (sampling) x = x * inv_t;                                          // TemperatureLogitsWarper (x / T)
+      if (sn[i] && theta != 1.0f) x = (x < 0.f) ? x * theta : x / theta;  // RepetitionPenaltyLogitsProcessor
+      if (sampling) x = x * inv_t;                                        // TemperatureLogitsWarper (x / T)
       if (x > best || (x == best && v < besti)) {
         best = x;
         besti = v;
@@ -1080,28 +1097,26 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerState s) {
   __syncthreads();
   if (threadIdx.x == 0) {
     int tok = tok_s;
-    if (s.finished[slot]) tok = s.stop;  // finished rows keep emitting pad == stop (generation_utils.py:3255-3256)
-    if (s.forced[slot] >= 0) {
-      tok = s.forced[slot];
+    if (st_finished) tok = s.stop;  // finished rows keep emitting pad == stop (generation_utils.py:3255-3256)
+    if (st_forced >= 0) {
+      tok = st_forced;
       s.forced[slot] = -1;
     }
-    const int k = s.gen_count[slot] + 1;  // this is the k-th generated token
+    const int k = st_gen + 1;  // this is the k-th generated token
     if (k <= s.max_new) s.tokens[(size_t)slot * s.max_new + k - 1] = tok;
     s.seen[(size_t)slot * s.V + tok] = 1;
     if (tok == s.stop) s.finished[slot] = 1;
     s.gen_count[slot] = k;
-    s.cur_len[slot] = s.prompt_len[slot] + k - 1;
+    s.cur_len[slot] = st_prompt + k - 1;
     tok_s = tok;
   }
   __syncthreads();
   // embed: mel_embedding[tok] + mel_pos_embedding[k + 1]   (model_v2.py:156-160)
-  const int tok = tok_s;
-  const int k = s.gen_count[slot];
-  const int pos = min(k + 1, s.n_pos - 1);
-  const float* e = s.mel_emb + (size_t)tok * s.D;
-  const float* pe = s.mel_pos + (size_t)pos * s.D;
+  const float* e = s.mel_emb + (size_t)tok_s * s.D;
   float* h = s.h + (size_t)slot * s.D;
-  for (int i = threadIdx.x; i < s.D; i += 1024) h[i] = e[i] + pe[i];
+  if ((int)threadIdx.x < s.D) h[threadIdx.x] = e[threadIdx.x] + pe0;
+  if ((int)threadIdx.x + 1024 < s.D) h[threadIdx.x + 1024] = e[threadIdx.x + 1024] + pe1;
+  for (int i = threadIdx.x + 2048; i < s.D; i += 1024) h[i] = e[i] + pe[i];
 }
 
 // copy one embedding row into the residual stream of `slot` and set its KV position
