@@ -322,7 +322,36 @@ static int run_conv(ixtts_bigvgan* h, const std::string& name, const float* x, f
     p.Nq = Tin + p.ntap;  // q up to Tin-1+ (ntap-1) still touches valid inputs; extra column is masked
     p.nphase = d.stride;
   }
-  return launch_conv1d(p, st);
+  static const bool timing = getenv("IXTTS_BV_TIMING") != nullptr;  // developer table: per conv shape, time and TFLOP/s
+  if (!timing) return launch_conv1d(p, st);
+  static std::map<std::string, std::pair<double, double>> table;  // shape -> (us, flops)
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipEventRecord(e0, st);
+  const int rc = launch_conv1d(p, st);
+  hipEventRecord(e1, st);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  char key[128];
+  snprintf(key, sizeof(key), "Cin %4d Cout %4d k %2d dil %2d stride %d T %7d", d.Cin, d.Cout, d.K, d.dil, d.stride, p.Tout);
+  auto& t = table[key];
+  t.first += ms * 1e3;
+  t.second += 2.0 * d.Cin * d.Cout * d.K * (double)Tin * B;
+  if (name == "resblocks." + std::to_string(h->cfg.n_stages * h->cfg.n_resblock_kernels - 1) + ".convs2.2") {
+    double tu = 0, tf = 0;
+    for (auto& kv : table) {
+      fprintf(stderr, "[bv] %s : %9.1f us  %6.1f TFLOP/s\n", kv.first.c_str(), kv.second.first, kv.second.second / kv.second.first / 1e6);
+      tu += kv.second.first;
+      tf += kv.second.second;
+    }
+    fprintf(stderr, "[bv] convs total %.1f us, %.1f TFLOP/s\n", tu, tf / tu / 1e6);
+    table.clear();
+  }
+  return rc;
 }
 
 extern "C" int ixtts_bigvgan_forward(ixtts_bigvgan* h, const float* mel, int B, int F, float* wav, void* stream) {
