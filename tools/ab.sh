@@ -1,2 +1,2 @@
-timeout -k 10 900 python -m pytest tests/test_gpu_gpt.py -m gpu -x -q > gpurun_out/t.log 2>&1; tail -2 gpurun_out/t.log
-timeout -k 10 280 python tools/quick_perf.py gpt bf16only 2>&1 | grep "gpt bf16"
+python tools/prof_rows.py 2>&1 | grep prefill
+timeout -k 10 900 python -m pytest tests/test_gpu_gpt.py tests/test_gpu_fullsize.py -m gpu -x -q > gpurun_out/t.log 2>&1; tail -5 gpurun_out/t.log

@@ -25,8 +25,8 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float a, float b) {
 }
 
 // ---- (x - mean) * rstd per row (gain/bias are folded into the next matrix); one wave per row
-template <int K>
-__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int T) {
+template <int K, typename OT = float>
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, OT* __restrict__ y, int T) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= T) return;
@@ -47,9 +47,9 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
     q = fmaf(d, d, q);
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / K) + 1e-5f);
-  float* yr = y + (size_t)row * K;
+  OT* yr = y + (size_t)row * K;
 #pragma unroll
-  for (int i = 0; i < PL; ++i) yr[lane + 64 * i] = (v[i] - mean) * rstd;
+  for (int i = 0; i < PL; ++i) store_kv(yr + lane + 64 * i, (v[i] - mean) * rstd);
 }
 
 // ---- ln_f (explicit affine) then final_norm (explicit affine) per row -> latent rows
@@ -255,16 +255,132 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     }
 }
 
+// ---- bf16 GEMM of the rows path: C[T][N] = A16[T][K] . Wt[N][K]^T (+ epilogue), tile 128 x 128 x 64, 4 waves (2 x 2),
+// wave tile 64 x 64 on v_mfma_f32_32x32x16_bf16.  Both operands are bf16 in global memory (the LayerNorm / attention /
+// gelu producers write bf16 rows), so a k-tile is 32 one-KiB pieces copied global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPRs, no ds_write pass), two LDS buffers, the copy of k-tile i+1 in flight under the MFMAs
+// of k-tile i (raw s_barrier + counted vmcnt: a __syncthreads would drain the copy).  The LDS image is row-linear (what
+// the DMA writes); the 16-byte granule g of row r sits at position g ^ (r & 7) -- swizzled on the SOURCE address and on
+// the fragment read -- so the 8 rows one ds_read_b128 cycle serves fall in 8 different bank groups.
+struct GemmArgs16 {
+  const unsigned short* A;  // [T][K] bf16
+  const unsigned short* wt; // [N][K] bf16
+  const float* bias;        // [N]
+  void* out;                // RE_QKV: q fp32 [T][D]; RE_RESID: x fp32 [T][N] (+=); RE_GELU: ff bf16 [T][N]
+  void* kcache;             // RE_QKV: slot+layer base [H][smax][64]
+  void* vcache;
+  int T, N, K, pos0, smax, D;
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int EPI, typename KVT>
+__global__ __launch_bounds__(256) void gemm_rows_bf16_kernel(GemmArgs16 g) {
+  constexpr int BM = 128, BN = 128, BK = 64, TILE = BM * BK * 2;  // 16 KiB per operand tile
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2][2][TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.f;
+
+  // this wave's 4 + 4 DMA pieces of a k-tile: piece c covers rows 8c .. 8c+7, lane -> (row, swizzled granule)
+  const unsigned short* asrc[4];
+  const unsigned short* wsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int gran = (lane & 7) ^ (row & 7);
+    asrc[i] = g.A + (size_t)min(m0 + row, g.T - 1) * g.K + gran * 8;  // rows beyond T repeat the last one; never stored
+    wsrc[i] = g.wt + (size_t)min(n0 + row, g.N - 1) * g.K + gran * 8;
+  }
+  auto issue = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(asrc[i] + kt * BK, &smem[buf][0][(wave * 4 + i) * 1024]);
+      glds16(wsrc[i] + kt * BK, &smem[buf][1][(wave * 4 + i) * 1024]);
+    }
+  };
+  const int nkt = g.K / BK;
+  issue(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    issue(min(kt + 1, nkt - 1), (kt + 1) & 1);  // (the last iteration re-copies its own tile into the idle buffer: keeps the count fixed)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // everything but the 8 pieces just issued has landed
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* At = smem[kt & 1][0];
+    const unsigned char* Wt = smem[kt & 1][1];
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int row = wm * 64 + mi * 32 + l31;
+        a[mi] = *reinterpret_cast<const bf16x8*>(At + row * 128 + (((kk * 2 + lh) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = wn * 64 + j * 32 + l31;
+        b[j] = *reinterpret_cast<const bf16x8*>(Wt + row * 128 + (((kk * 2 + lh) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[j], acc[mi][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();  // every wave is done with this buffer before the next iteration's copy lands in it
+  }
+  // ---- epilogue (C layout: col = lane&31 -> n, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> m)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + l31;
+      if (n >= g.N) continue;
+      const float bias = g.bias[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= g.T) continue;
+        const float v = acc[mi][j][r] + bias;
+        if constexpr (EPI == RE_RESID) {
+          float* o = reinterpret_cast<float*>(g.out) + (size_t)m * g.N + n;
+          *o = *o + v;
+        } else if constexpr (EPI == RE_GELU) {
+          store_kv(reinterpret_cast<bf16*>(g.out) + (size_t)m * g.N + n, gelu_new_f(v));
+        } else {
+          if (n < g.D) {
+            reinterpret_cast<float*>(g.out)[(size_t)m * g.D + n] = v;
+          } else {
+            const int which = n / g.D;
+            const int c = n - which * g.D;
+            const int hh = c / HD, d = c % HD;
+            KVT* cache = reinterpret_cast<KVT*>(which == 1 ? g.kcache : g.vcache);
+            store_kv(cache + ((size_t)hh * g.smax + g.pos0 + m) * HD + d, v);
+          }
+        }
+      }
+    }
+}
+
 // ---- causal attention over rows: grid (H, T); row t attends keys [valid_from, pos0 + t]
 struct AttnRowsArgs {
   const float* q;      // [T][D]
   const void* kcache;  // slot+layer base [H][smax][64]
   const void* vcache;
-  float* out;          // [T][D]
+  void* out;           // [T][D], fp32 or bf16 (OT)
   int T, D, smax, pos0, valid_from;
 };
 
-template <typename KVT>
+template <typename KVT, typename OT = float>
 __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsArgs a) {
   constexpr int NW = 4;
   using LY = KVLayout<KVT>;
@@ -284,7 +400,7 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsArgs a) {
     hi = hi0;
   });
   const float o = attn_merge<KVT, NW>(st, sm, wave, lane);
-  if (threadIdx.x < 64) a.out[(size_t)row * a.D + hh * HD + threadIdx.x] = o;
+  if (threadIdx.x < 64) store_kv(reinterpret_cast<OT*>(a.out) + (size_t)row * a.D + hh * HD + threadIdx.x, o);
 }
 
 template <typename WT, typename KVT, int EPI>
@@ -325,14 +441,51 @@ static int forward_rows_t(ixtts_gpt* h, int slot, int T, int pos0, int valid_fro
   return IXTTS_OK;
 }
 
+// bf16 weights: the producers write bf16 rows (into the same workspaces) and the GEMMs are the LDS-DMA kernel
+template <int D>
+static int forward_rows_bf16(ixtts_gpt* h, int slot, int T, int pos0, int valid_from, hipStream_t st) {
+  using KVT = bf16;
+  const size_t lstride = (size_t)h->slots * D * h->smax * sizeof(KVT);
+  const size_t sstride = (size_t)D * h->smax * sizeof(KVT);
+  bf16* xn16 = reinterpret_cast<bf16*>(h->rxn);
+  bf16* att16 = reinterpret_cast<bf16*>(h->ratt);
+  bf16* ff16 = reinterpret_cast<bf16*>(h->rff);
+  const dim3 blk(256);
+  auto grid = [&](int N) { return dim3(ceil_div(N, 128), ceil_div(T, 128)); };
+  for (int l = 0; l < h->L; ++l) {
+    const LayerOff& o = h->lo[l];
+    uint8_t* kc = (uint8_t*)h->kc + l * lstride + slot * sstride;
+    uint8_t* vc = (uint8_t*)h->vc + l * lstride + slot * sstride;
+    hipLaunchKernelGGL((ln_rows_kernel<D, bf16>), dim3(ceil_div(T, 4)), blk, 0, st, h->rx, xn16, T);
+    GemmArgs16 g;
+    g.A = reinterpret_cast<const unsigned short*>(xn16); g.wt = reinterpret_cast<const unsigned short*>(A_PTR(o.wqkv)); g.bias = A_F32(o.bqkv);
+    g.out = h->rq; g.kcache = kc; g.vcache = vc; g.T = T; g.N = 3 * D; g.K = D; g.pos0 = pos0; g.smax = h->smax; g.D = D;
+    hipLaunchKernelGGL((gemm_rows_bf16_kernel<RE_QKV, KVT>), grid(g.N), blk, 0, st, g);
+    AttnRowsArgs a;
+    a.q = h->rq; a.kcache = kc; a.vcache = vc; a.out = att16; a.T = T; a.D = D; a.smax = h->smax; a.pos0 = pos0; a.valid_from = valid_from;
+    hipLaunchKernelGGL((attn_rows_kernel<KVT, bf16>), dim3(h->H, T), blk, 0, st, a);
+    g.A = reinterpret_cast<const unsigned short*>(att16); g.wt = reinterpret_cast<const unsigned short*>(A_PTR(o.wo)); g.bias = A_F32(o.bo);
+    g.out = h->rx; g.N = D; g.K = D;
+    hipLaunchKernelGGL((gemm_rows_bf16_kernel<RE_RESID, KVT>), grid(g.N), blk, 0, st, g);
+    hipLaunchKernelGGL((ln_rows_kernel<D, bf16>), dim3(ceil_div(T, 4)), blk, 0, st, h->rx, xn16, T);
+    g.A = reinterpret_cast<const unsigned short*>(xn16); g.wt = reinterpret_cast<const unsigned short*>(A_PTR(o.wfc)); g.bias = A_F32(o.bfc);
+    g.out = ff16; g.N = 4 * D; g.K = D;
+    hipLaunchKernelGGL((gemm_rows_bf16_kernel<RE_GELU, KVT>), grid(g.N), blk, 0, st, g);
+    g.A = reinterpret_cast<const unsigned short*>(ff16); g.wt = reinterpret_cast<const unsigned short*>(A_PTR(o.wpr)); g.bias = A_F32(o.bpr);
+    g.out = h->rx; g.N = D; g.K = 4 * D;
+    hipLaunchKernelGGL((gemm_rows_bf16_kernel<RE_RESID, KVT>), grid(g.N), blk, 0, st, g);
+  }
+  IX_HIP(hipGetLastError());
+  return IXTTS_OK;
+}
+
 int forward_rows(ixtts_gpt* h, int slot, int T, int pos0, int valid_from, hipStream_t st) {
   if (T <= 0) return IXTTS_OK;
   if (h->cfg.weight_dtype == IXTTS_DTYPE_F32) {
     return h->D == 1280 ? forward_rows_t<float, float, 1280>(h, slot, T, pos0, valid_from, st)
                         : forward_rows_t<float, float, 128>(h, slot, T, pos0, valid_from, st);
   }
-  return h->D == 1280 ? forward_rows_t<bf16, bf16, 1280>(h, slot, T, pos0, valid_from, st)
-                      : forward_rows_t<bf16, bf16, 128>(h, slot, T, pos0, valid_from, st);
+  return h->D == 1280 ? forward_rows_bf16<1280>(h, slot, T, pos0, valid_from, st) : forward_rows_bf16<128>(h, slot, T, pos0, valid_from, st);
 }
 
 int final_norm_rows(ixtts_gpt* h, const float* x, float* y, int T, hipStream_t st) {
