@@ -22,7 +22,7 @@ if TRACE:
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-Wno-unused-value", "-fno-gpu-rdc",
          # first 16 kernarg dwords arrive in SGPRs with the wave (no s_load round trip before the first global loads)
-         "-mllvm", "-amdgpu-kernarg-preload-count=16"] + (["-DIXTTS_TRACE"] + os.environ.get("IXTTS_EXP", "").split() if TRACE else [])
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"] + (["-DIXTTS_TRACE"] if TRACE else []) + os.environ.get("IXTTS_EXP", "").split()
 
 
 def _sources():

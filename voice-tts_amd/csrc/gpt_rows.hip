@@ -258,10 +258,13 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
 // ---- bf16 GEMM of the rows path: C[T][N] = A16[T][K] . Wt[N][K]^T (+ epilogue), tile 128 x 128 x 64, 4 waves (2 x 2),
 // wave tile 64 x 64 on v_mfma_f32_32x32x16_bf16.  Both operands are bf16 in global memory (the LayerNorm / attention /
 // gelu producers write bf16 rows), so a k-tile is 32 one-KiB pieces copied global -> LDS by LDS-DMA
-// (global_load_lds_dwordx4: no VGPRs, no ds_write pass), two LDS buffers, the copy of k-tile i+1 in flight under the MFMAs
-// of k-tile i (raw s_barrier + counted vmcnt: a __syncthreads would drain the copy).  The LDS image is row-linear (what
-// the DMA writes); the 16-byte granule g of row r sits at position g ^ (r & 7) -- swizzled on the SOURCE address and on
-// the fragment read -- so the 8 rows one ds_read_b128 cycle serves fall in 8 different bank groups.
+// (global_load_lds_dwordx4: no VGPRs, no ds_write pass) into two LDS buffers: the copy of k-tile i+1 is in flight under the
+// MFMAs of k-tile i (raw s_barrier + counted vmcnt: a __syncthreads would drain it).  (A ring of 4 buffers measured the
+// same: the copies are not what bounds the loop.)  The LDS image is row-linear (what
+// the DMA writes); the 16-byte granule g of row r sits at position g ^ ((r >> 1) & 7) -- swizzled on the SOURCE address
+// and on the fragment read.  A ds_read_b128 is served in 4 groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32)
+// over 64 banks = 16 granules: with 128-byte rows the granule slot is 8 (r & 1) + position, and (r >> 1) & 7 takes 8
+// different values over each group's even rows and over its odd rows -> conflict-free (g ^ (r & 7) was 2-way: PMC).
 struct GemmArgs16 {
   const unsigned short* A;  // [T][K] bf16
   const unsigned short* wt; // [N][K] bf16
@@ -276,10 +279,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+constexpr int G16_NBUF = 2;                       // LDS buffers: NBUF - 1 k-tiles of copies in flight under the MFMAs
+constexpr int G16_TILE = 128 * 64 * 2;            // 16 KiB per operand tile
+constexpr int G16_SMEM = G16_NBUF * 2 * G16_TILE; // 64 KiB: two workgroups per CU
+
 template <int EPI, typename KVT>
 __global__ __launch_bounds__(256) void gemm_rows_bf16_kernel(GemmArgs16 g) {
-  constexpr int BM = 128, BN = 128, BK = 64, TILE = BM * BK * 2;  // 16 KiB per operand tile
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2][2][TILE];
+  constexpr int BM = 128, BN = 128, BK = 64, TILE = G16_TILE, NBUF = G16_NBUF;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+  unsigned char (*smem)[2][TILE] = reinterpret_cast<unsigned char (*)[2][TILE]>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(256) void gemm_rows_bf16_kernel(GemmArgs16 g) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (wave * 4 + i) * 8 + (lane >> 3);
-    const int gran = (lane & 7) ^ (row & 7);
+    const int gran = (lane & 7) ^ ((row >> 1) & 7);
     asrc[i] = g.A + (size_t)min(m0 + row, g.T - 1) * g.K + gran * 8;  // rows beyond T repeat the last one; never stored
     wsrc[i] = g.wt + (size_t)min(n0 + row, g.N - 1) * g.K + gran * 8;
   }
@@ -311,25 +319,28 @@ __global__ __launch_bounds__(256) void gemm_rows_bf16_kernel(GemmArgs16 g) {
     }
   };
   const int nkt = g.K / BK;
-  issue(0, 0);
+#pragma unroll
+  for (int p = 0; p < NBUF - 1; ++p) issue(min(p, nkt - 1), p);
   for (int kt = 0; kt < nkt; ++kt) {
-    issue(min(kt + 1, nkt - 1), (kt + 1) & 1);  // (the last iteration re-copies its own tile into the idle buffer: keeps the count fixed)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // everything but the 8 pieces just issued has landed
+    // (past the end the last tile is re-copied into an idle buffer: keeps the outstanding count fixed)
+    issue(min(kt + NBUF - 1, nkt - 1), (kt + NBUF - 1) % NBUF);
+    static_assert(NBUF == 2, "the immediate below is 8 * (NBUF - 1)");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // everything but the youngest k-tile (8 pieces) has landed
     __builtin_amdgcn_s_barrier();
-    const unsigned char* At = smem[kt & 1][0];
-    const unsigned char* Wt = smem[kt & 1][1];
+    const unsigned char* At = smem[kt % NBUF][0];
+    const unsigned char* Wt = smem[kt % NBUF][1];
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       bf16x8 a[2], b[2];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         const int row = wm * 64 + mi * 32 + l31;
-        a[mi] = *reinterpret_cast<const bf16x8*>(At + row * 128 + (((kk * 2 + lh) ^ (row & 7)) << 4));
+        a[mi] = *reinterpret_cast<const bf16x8*>(At + row * 128 + (((kk * 2 + lh) ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int row = wn * 64 + j * 32 + l31;
-        b[j] = *reinterpret_cast<const bf16x8*>(Wt + row * 128 + (((kk * 2 + lh) ^ (row & 7)) << 4));
+        b[j] = *reinterpret_cast<const bf16x8*>(Wt + row * 128 + (((kk * 2 + lh) ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
@@ -338,37 +349,66 @@ __global__ __launch_bounds__(256) void gemm_rows_bf16_kernel(GemmArgs16 g) {
     }
     __builtin_amdgcn_s_barrier();  // every wave is done with this buffer before the next iteration's copy lands in it
   }
-  // ---- epilogue (C layout: col = lane&31 -> n, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> m)
+  // ---- epilogue (C layout: col = lane&31 -> n, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> m).  Loads first, all of them,
+  // unconditionally (indices clamped): a residual load under the row-bound branch was waited for on the spot, 64 dependent
+  // round trips per lane (~25 us per launch whatever the GEMM size).  Only the stores are predicated.
+  float bias[2];
+  int ncol[2];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int j = 0; j < 2; ++j) {
+    ncol[j] = n0 + wn * 64 + j * 32 + l31;
+    bias[j] = g.bias[min(ncol[j], g.N - 1)];
+  }
+  if constexpr (EPI == RE_RESID) {
+    float* xo = reinterpret_cast<float*>(g.out);
+    float old[2][2][16];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + l31;
-      if (n >= g.N) continue;
-      const float bias = g.bias[n];
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= g.T) continue;
-        const float v = acc[mi][j][r] + bias;
-        if constexpr (EPI == RE_RESID) {
-          float* o = reinterpret_cast<float*>(g.out) + (size_t)m * g.N + n;
-          *o = *o + v;
-        } else if constexpr (EPI == RE_GELU) {
-          store_kv(reinterpret_cast<bf16*>(g.out) + (size_t)m * g.N + n, gelu_new_f(v));
-        } else {
-          if (n < g.D) {
-            reinterpret_cast<float*>(g.out)[(size_t)m * g.D + n] = v;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = min(m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, g.T - 1);
+          old[mi][j][r] = xo[(size_t)m * g.N + min(ncol[j], g.N - 1)];
+        }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < g.T && ncol[j] < g.N) xo[(size_t)m * g.N + ncol[j]] = old[mi][j][r] + (acc[mi][j][r] + bias[j]);
+        }
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = ncol[j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m >= g.T || n >= g.N) continue;
+          const float v = acc[mi][j][r] + bias[j];
+          if constexpr (EPI == RE_GELU) {
+            // gelu_new(v) = v * sigmoid(2u), u = sqrt(2/pi) (v + 0.044715 v^3): one exp instead of tanhf (the result is rounded to bf16)
+            const float u2 = 1.5957691216057308f * (v + 0.044715f * v * v * v);
+            store_kv(reinterpret_cast<bf16*>(g.out) + (size_t)m * g.N + n, v / (1.0f + __expf(-u2)));
           } else {
-            const int which = n / g.D;
-            const int c = n - which * g.D;
-            const int hh = c / HD, d = c % HD;
-            KVT* cache = reinterpret_cast<KVT*>(which == 1 ? g.kcache : g.vcache);
-            store_kv(cache + ((size_t)hh * g.smax + g.pos0 + m) * HD + d, v);
+            if (n < g.D) {
+              reinterpret_cast<float*>(g.out)[(size_t)m * g.D + n] = v;
+            } else {
+              const int which = n / g.D;
+              const int c = n - which * g.D;
+              const int hh = c / HD, d = c % HD;
+              KVT* cache = reinterpret_cast<KVT*>(which == 1 ? g.kcache : g.vcache);
+              store_kv(cache + ((size_t)hh * g.smax + g.pos0 + m) * HD + d, v);
+            }
           }
         }
       }
-    }
+  }
 }
 
 // ---- causal attention over rows: grid (H, T); row t attends keys [valid_from, pos0 + t]
@@ -452,6 +492,13 @@ static int forward_rows_bf16(ixtts_gpt* h, int slot, int T, int pos0, int valid_
   bf16* ff16 = reinterpret_cast<bf16*>(h->rff);
   const dim3 blk(256);
   auto grid = [&](int N) { return dim3(ceil_div(N, 128), ceil_div(T, 128)); };
+  static bool attr_done = false;
+  if (!attr_done) {
+    IX_HIP(hipFuncSetAttribute((const void*)gemm_rows_bf16_kernel<RE_QKV, KVT>, hipFuncAttributeMaxDynamicSharedMemorySize, G16_SMEM));
+    IX_HIP(hipFuncSetAttribute((const void*)gemm_rows_bf16_kernel<RE_RESID, KVT>, hipFuncAttributeMaxDynamicSharedMemorySize, G16_SMEM));
+    IX_HIP(hipFuncSetAttribute((const void*)gemm_rows_bf16_kernel<RE_GELU, KVT>, hipFuncAttributeMaxDynamicSharedMemorySize, G16_SMEM));
+    attr_done = true;
+  }
   for (int l = 0; l < h->L; ++l) {
     const LayerOff& o = h->lo[l];
     uint8_t* kc = (uint8_t*)h->kc + l * lstride + slot * sstride;
@@ -460,20 +507,20 @@ static int forward_rows_bf16(ixtts_gpt* h, int slot, int T, int pos0, int valid_
     GemmArgs16 g;
     g.A = reinterpret_cast<const unsigned short*>(xn16); g.wt = reinterpret_cast<const unsigned short*>(A_PTR(o.wqkv)); g.bias = A_F32(o.bqkv);
     g.out = h->rq; g.kcache = kc; g.vcache = vc; g.T = T; g.N = 3 * D; g.K = D; g.pos0 = pos0; g.smax = h->smax; g.D = D;
-    hipLaunchKernelGGL((gemm_rows_bf16_kernel<RE_QKV, KVT>), grid(g.N), blk, 0, st, g);
+    hipLaunchKernelGGL((gemm_rows_bf16_kernel<RE_QKV, KVT>), grid(g.N), blk, G16_SMEM, st, g);
     AttnRowsArgs a;
     a.q = h->rq; a.kcache = kc; a.vcache = vc; a.out = att16; a.T = T; a.D = D; a.smax = h->smax; a.pos0 = pos0; a.valid_from = valid_from;
     hipLaunchKernelGGL((attn_rows_kernel<KVT, bf16>), dim3(h->H, T), blk, 0, st, a);
     g.A = reinterpret_cast<const unsigned short*>(att16); g.wt = reinterpret_cast<const unsigned short*>(A_PTR(o.wo)); g.bias = A_F32(o.bo);
     g.out = h->rx; g.N = D; g.K = D;
-    hipLaunchKernelGGL((gemm_rows_bf16_kernel<RE_RESID, KVT>), grid(g.N), blk, 0, st, g);
+    hipLaunchKernelGGL((gemm_rows_bf16_kernel<RE_RESID, KVT>), grid(g.N), blk, G16_SMEM, st, g);
     hipLaunchKernelGGL((ln_rows_kernel<D, bf16>), dim3(ceil_div(T, 4)), blk, 0, st, h->rx, xn16, T);
     g.A = reinterpret_cast<const unsigned short*>(xn16); g.wt = reinterpret_cast<const unsigned short*>(A_PTR(o.wfc)); g.bias = A_F32(o.bfc);
     g.out = ff16; g.N = 4 * D; g.K = D;
-    hipLaunchKernelGGL((gemm_rows_bf16_kernel<RE_GELU, KVT>), grid(g.N), blk, 0, st, g);
+    hipLaunchKernelGGL((gemm_rows_bf16_kernel<RE_GELU, KVT>), grid(g.N), blk, G16_SMEM, st, g);
     g.A = reinterpret_cast<const unsigned short*>(ff16); g.wt = reinterpret_cast<const unsigned short*>(A_PTR(o.wpr)); g.bias = A_F32(o.bpr);
     g.out = h->rx; g.N = D; g.K = 4 * D;
-    hipLaunchKernelGGL((gemm_rows_bf16_kernel<RE_RESID, KVT>), grid(g.N), blk, 0, st, g);
+    hipLaunchKernelGGL((gemm_rows_bf16_kernel<RE_RESID, KVT>), grid(g.N), blk, G16_SMEM, st, g);
   }
   IX_HIP(hipGetLastError());
   return IXTTS_OK;
