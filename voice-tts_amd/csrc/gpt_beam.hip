@@ -31,6 +31,9 @@ struct BeamArgs {
   int* done;
   int32_t* forced;      // [2*NB] flat picks (beam*V + token) for the next step, valid when *forced_flag != 0
   int* forced_flag;
+  float* cand_v;        // [NB][SAMP_MAXK] processed scores of each beam's surviving tokens, descending
+  int* cand_i;          // [NB][SAMP_MAXK] their token ids
+  int* cand_n;          // [NB] how many survive TopK + TopP
   int NB;
 };
 
@@ -53,52 +56,43 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {
   return s;
 }
 
-__global__ __launch_bounds__(1024) void beam_step_kernel(BeamArgs a) {
+// Phase A, one workgroup per beam: log_softmax -> penalty -> temperature -> TopK (min keep 2) -> TopP (min keep 2); the
+// survivors go to global memory sorted by score.  (As one workgroup looping over the beams, with the TopP sums on one
+// thread, the whole step took 164 us at 3 beams.)
+__global__ __launch_bounds__(1024) void beam_cand_kernel(BeamArgs a) {
   __shared__ float red[16];
   __shared__ unsigned int hist[256];
   __shared__ unsigned int sel_prefix, sel_remaining;
-  __shared__ float cand_v[SAMP_MAXK], sort_v[SAMP_MAXK];
+  __shared__ float cand_v[SAMP_MAXK], sort_v[SAMP_MAXK], ev[SAMP_MAXK];
   __shared__ int cand_i[SAMP_MAXK], sort_i[SAMP_MAXK];
   __shared__ int cand_n;
-  __shared__ float j_score[JOINT_MAX], j_key[JOINT_MAX];
-  __shared__ int j_flat[JOINT_MAX];
-  __shared__ int j_n, keep_s;
-  __shared__ float pick_score[2 * BEAM_MAX];
-  __shared__ int pick_flat[2 * BEAM_MAX], pick_sorted[2 * BEAM_MAX];
-  __shared__ float nb_score[BEAM_MAX];
-  __shared__ int nb_tok[BEAM_MAX], nb_src[BEAM_MAX];
-  __shared__ int act;  // 0: frozen (already done), 1: step taken, 2: became done this step
+  __shared__ float Z_s;
 
   const SamplerState& s = a.s;
-  const int NB = a.NB;
+  const int b = blockIdx.x;
+  const int V = s.V;
+  // every load whose address is known at entry, up front and unconditionally
+  const float* lg = s.logits + (size_t)b * V;
+  const uint8_t* seen = s.seen + (size_t)b * V;
+  float vals[SAMP_PT];
+  uint8_t sn[SAMP_PT];
+#pragma unroll
+  for (int i = 0; i < SAMP_PT; ++i) {
+    const int v = min((int)threadIdx.x + i * 1024, V - 1);
+    vals[i] = lg[v];
+    sn[i] = seen[v];
+  }
   const ixtts_sampler_cfg cfg = *s.cfg;
+  const int done = *a.done;
+  __builtin_amdgcn_sched_barrier(0);
+  if (done) return;  // hypotheses complete: HF leaves the loop here; later graph replays are no-ops
   const float theta = cfg.repetition_penalty;
   const float inv_t = cfg.temperature > 0.f ? 1.0f / cfg.temperature : 1.0f;
-  const int V = s.V;
-  if (threadIdx.x == 0) {
-    j_n = 0;
-    act = (*a.done) ? 0 : 1;
-  }
-  __syncthreads();
-  if (act == 0) {  // hypotheses complete: HF leaves the loop here; later graph replays are no-ops
-    if (threadIdx.x < NB) {
-      a.src[threadIdx.x] = threadIdx.x;
-      s.finished[threadIdx.x] = 1;
-    }
-    return;
-  }
-  const int kstep = s.gen_count[0] + 1;  // this step appends the k-th generated token
-
-  // ---- per beam: log_softmax -> penalty -> temperature -> TopK (min keep 2) -> TopP (min keep 2)
-  for (int b = 0; b < NB; ++b) {
-    const float* lg = s.logits + (size_t)b * V;
-    const uint8_t* seen = s.seen + (size_t)b * V;
-    float vals[SAMP_PT];
+  {
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < SAMP_PT; ++i) {
-      const int v = threadIdx.x + i * 1024;
-      vals[i] = v < V ? lg[v] : -INFINITY;
+      if ((int)threadIdx.x + i * 1024 >= V) vals[i] = -INFINITY;
       mx = fmaxf(mx, vals[i]);
     }
     mx = block_max_1024(mx, red);
@@ -113,7 +107,7 @@ __global__ __launch_bounds__(1024) void beam_step_kernel(BeamArgs a) {
       if (v < V) {
         x = vals[i] - lse;  // log_softmax
         if (cfg.suppress_stop && v == s.stop) x = -INFINITY;
-        if (seen[v] && theta != 1.0f) x = (x < 0.f) ? x * theta : x / theta;
+        if (sn[i] && theta != 1.0f) x = (x < 0.f) ? x * theta : x / theta;
         x *= inv_t;
       }
       vals[i] = x;
@@ -174,33 +168,75 @@ __global__ __launch_bounds__(1024) void beam_step_kernel(BeamArgs a) {
       sort_i[rank] = mi;
     }
     __syncthreads();
+    // TopP: the exponentials and quotients in parallel, the two running sums in the reference's order on one thread
+    if (threadIdx.x < n) ev[threadIdx.x] = expf(sort_v[threadIdx.x] - sort_v[0]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float Z = 0.f;
+      for (int r = 0; r < n; ++r) Z += ev[r];
+      Z_s = Z;
+    }
+    __syncthreads();
+    if (threadIdx.x < n) ev[threadIdx.x] = ev[threadIdx.x] / Z_s;
+    __syncthreads();
     if (threadIdx.x == 0) {
       int keep = n;
       if (cfg.top_p < 1.0f && n > 0) {
-        const float m0 = sort_v[0];
-        float Z = 0.f;
-        for (int r = 0; r < n; ++r) Z += expf(sort_v[r] - m0);
         float tail = 0.f;
         for (int r = n - 1; r >= 2; --r) {  // never remove the top min_tokens_to_keep = 2
-          tail += expf(sort_v[r] - m0) / Z;
+          tail += ev[r];
           if (tail <= 1.0f - cfg.top_p) keep = r;
           else break;
         }
       }
-      keep_s = keep;
+      a.cand_n[b] = keep;
     }
-    __syncthreads();
-    const int keep = keep_s;
-    const float bs = a.beam_scores[b];
-    const int off = j_n;
-    if (threadIdx.x < keep) {
-      j_score[off + threadIdx.x] = sort_v[threadIdx.x] + bs;  // fp32 add, as next_token_scores_processed + beam_scores
-      j_flat[off + threadIdx.x] = b * V + sort_i[threadIdx.x];
+    if (threadIdx.x < n) {
+      a.cand_v[b * SAMP_MAXK + threadIdx.x] = sort_v[threadIdx.x];
+      a.cand_i[b * SAMP_MAXK + threadIdx.x] = sort_i[threadIdx.x];
     }
-    __syncthreads();
-    if (threadIdx.x == 0) j_n = off + keep;
-    __syncthreads();
   }
+}
+
+// Phase B, one workgroup: joint draw over the beams' survivors, BeamSearchScorer.process, histories, embeddings.
+__global__ __launch_bounds__(1024) void beam_step_kernel(BeamArgs a) {
+  __shared__ float j_score[JOINT_MAX], j_key[JOINT_MAX];
+  __shared__ int j_flat[JOINT_MAX];
+  __shared__ int j_n;
+  __shared__ float pick_score[2 * BEAM_MAX];
+  __shared__ int pick_flat[2 * BEAM_MAX], pick_sorted[2 * BEAM_MAX];
+  __shared__ float nb_score[BEAM_MAX];
+  __shared__ int nb_tok[BEAM_MAX], nb_src[BEAM_MAX];
+  __shared__ int act;  // 0: frozen (already done), 1: step taken, 2: became done this step
+
+  const SamplerState& s = a.s;
+  const int NB = a.NB;
+  const ixtts_sampler_cfg cfg = *s.cfg;
+  const int V = s.V;
+  if (threadIdx.x == 0) act = (*a.done) ? 0 : 1;
+  __syncthreads();
+  if (act == 0) {  // hypotheses complete: HF leaves the loop here; later graph replays are no-ops
+    if (threadIdx.x < NB) {
+      a.src[threadIdx.x] = threadIdx.x;
+      s.finished[threadIdx.x] = 1;
+    }
+    return;
+  }
+  const int kstep = s.gen_count[0] + 1;  // this step appends the k-th generated token
+  {
+    int off = 0;
+    for (int b = 0; b < NB; ++b) {
+      const int keep = min(a.cand_n[b], SAMP_MAXK);
+      const float bs = a.beam_scores[b];
+      if ((int)threadIdx.x < keep) {
+        j_score[off + threadIdx.x] = a.cand_v[b * SAMP_MAXK + threadIdx.x] + bs;  // fp32 add, as next_token_scores_processed + beam_scores
+        j_flat[off + threadIdx.x] = b * V + a.cand_i[b * SAMP_MAXK + threadIdx.x];
+      }
+      off += keep;
+    }
+    if (threadIdx.x == 0) j_n = off;
+  }
+  __syncthreads();
 
   // ---- joint multinomial(2*NB) without replacement (Gumbel top-k == p / Exp(1) top-k), or the forced draws
   const int n_tot = j_n;
@@ -370,12 +406,18 @@ void launch_beam_step(ixtts_gpt* h, const SamplerState& s, hipStream_t st) {
   a.done = h->beam_done;
   a.forced = h->beam_forced;
   a.forced_flag = h->beam_forced_flag;
+  a.cand_v = h->beam_cand_v;
+  a.cand_i = h->beam_cand_i;
+  a.cand_n = h->beam_cand_n;
   a.NB = h->num_beams;
+  hipLaunchKernelGGL(beam_cand_kernel, dim3(h->num_beams), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(beam_step_kernel, dim3(1), dim3(1024), 0, st, a);
   const int row_bytes = HD * (int)h->esize;
   const size_t slot_stride = (size_t)h->D * h->smax * h->esize;
   const size_t layer_stride = (size_t)h->slots * slot_stride;
-  dim3 grid(ceil_div(h->smax * (row_bytes / 16), 256), h->H, h->L * 2);
+  // rows to move are bounded by the context bucket the graph is captured for (the host counts the steps it issues)
+  const int max_rows = h->attn_bucket < NBKT ? std::min(h->smax, attn_cover(h->attn_bucket)) : h->smax;
+  dim3 grid(ceil_div(max_rows * (row_bytes / 16), 256), h->H, h->L * 2);
   hipLaunchKernelGGL(beam_reorder_kv_kernel, grid, dim3(256), 0, st, h->kc, h->vc, (const int*)h->beam_src, (const int*)h->prompt_len,
                      (const int*)h->cur_len, (const int*)h->beam_done, h->num_beams, h->H, h->smax, layer_stride, slot_stride, row_bytes);
 }

@@ -88,6 +88,8 @@ struct ixtts_gpt {
   float *beam_scores = nullptr, *hyp_score = nullptr, *hyp_worst = nullptr;
   int *beam_src = nullptr, *hyp_len = nullptr, *n_hyp = nullptr, *beam_done = nullptr, *beam_forced_flag = nullptr;
   int32_t *hyp_tok = nullptr, *beam_forced = nullptr;
+  float* beam_cand_v = nullptr;  // [MAXB][SAMP_MAXK] per-beam survivors of a step (gpt_beam.hip)
+  int *beam_cand_i = nullptr, *beam_cand_n = nullptr;
   hipGraphExec_t beam_exec[ixtts::NBKT + 1] = {}, beam_multi_exec[ixtts::NBKT + 1] = {};
   int beam_exec_nb = 0;
   // batched-rows workspace (prefill / latent): [max_seq][D] x4 + [max_seq][4D]

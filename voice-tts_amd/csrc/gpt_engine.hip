@@ -360,6 +360,9 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   ok &= hipMalloc(&h->beam_forced_flag, 4) == hipSuccess;
   ok &= hipMalloc(&h->beam_forced, 2 * MAXB * 4) == hipSuccess;
   ok &= hipMalloc(&h->hyp_tok, (size_t)MAXB * h->smax * 4) == hipSuccess;
+  ok &= hipMalloc(&h->beam_cand_v, (size_t)MAXB * SAMP_MAXK * 4) == hipSuccess;
+  ok &= hipMalloc(&h->beam_cand_i, (size_t)MAXB * SAMP_MAXK * 4) == hipSuccess;
+  ok &= hipMalloc(&h->beam_cand_n, (size_t)MAXB * 4) == hipSuccess;
   ok &= hipMalloc(&h->probs, (size_t)S * V * 4) == hipSuccess;
   h->scratch_floats = (size_t)FF * D;
   ok &= hipMalloc(&h->scratch, h->scratch_floats * 4) == hipSuccess;
@@ -841,7 +844,7 @@ extern "C" int ixtts_gpt_destroy(ixtts_gpt* h) {
   if (h->cap_stream) hipStreamDestroy(h->cap_stream);
   void* ptrs[] = {h->arena, h->stage, h->kc, h->vc, h->h, h->q, h->ff, h->att, h->part, h->logits, h->rowbuf, h->cur_len, h->gen_count,
                   h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->probs, h->scratch, h->beam_scores, h->hyp_score, h->hyp_worst, h->beam_src, h->hyp_len,
-                  h->n_hyp, h->beam_done, h->beam_forced_flag, h->beam_forced, h->hyp_tok,
+                  h->n_hyp, h->beam_done, h->beam_forced_flag, h->beam_forced, h->hyp_tok, h->beam_cand_v, h->beam_cand_i, h->beam_cand_n,
                   h->rx, h->rxn, h->rq, h->ratt, h->rff};
   for (void* p : ptrs)
     if (p) hipFree(p);
