@@ -61,7 +61,7 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {
 // thread, the whole step took 164 us at 3 beams.)
 __global__ __launch_bounds__(1024) void beam_cand_kernel(BeamArgs a) {
   __shared__ float red[16];
-  __shared__ unsigned int hist[256];
+  __shared__ unsigned int hist[256], wtot[4];
   __shared__ unsigned int sel_prefix, sel_remaining;
   __shared__ float cand_v[SAMP_MAXK], sort_v[SAMP_MAXK], ev[SAMP_MAXK];
   __shared__ int cand_i[SAMP_MAXK], sort_i[SAMP_MAXK];
@@ -127,23 +127,11 @@ __global__ __launch_bounds__(1024) void beam_cand_kernel(BeamArgs a) {
 #pragma unroll
       for (int i = 0; i < SAMP_PT; ++i) {
         const int v = threadIdx.x + i * 1024;
-        if (v < V) {
-          const unsigned int key = f2key(vals[i]);
-          if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 0xffu], 1u);
-        }
+        const unsigned int key = f2key(vals[i]);
+        hist_add_aggregated(hist, (key >> shift) & 0xffu, v < V && (key & pmask) == prefix);
       }
       __syncthreads();
-      if (threadIdx.x == 0) {
-        unsigned int rem = sel_remaining, bin = 255;
-        for (;; --bin) {
-          const unsigned int c = hist[bin];
-          if (c >= rem || bin == 0) break;
-          rem -= c;
-        }
-        sel_prefix = prefix | (bin << shift);
-        sel_remaining = rem;
-      }
-      __syncthreads();
+      radix_pick_bin(hist, wtot, &sel_prefix, &sel_remaining, shift);
     }
     const unsigned int thr = sel_prefix;
 #pragma unroll
