@@ -359,6 +359,8 @@ __global__ __launch_bounds__(1024) void beam_step_kernel(BeamArgs a) {
   }
 }
 
+constexpr int REORDER_CPT = 4;
+
 // _reorder_cache: rows [prompt_len, cur_len) of every layer's K and V follow `src` (the prompt rows are
 // identical across beams).  grid (chunks, H, L*2); one 16-byte chunk per thread, all beams read before any write.
 __global__ __launch_bounds__(256) void beam_reorder_kv_kernel(void* kc, void* vc, const int* src, const int* prompt_len,
@@ -371,14 +373,21 @@ __global__ __launch_bounds__(256) void beam_reorder_kv_kernel(void* kc, void* vc
   const int p0 = prompt_len[0];
   const int rows = cur_len[0] - p0;  // generated rows already in the cache
   const int cpr = row_bytes / 16;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= rows * cpr) return;
   const int layer = blockIdx.z >> 1, is_v = blockIdx.z & 1, hh = blockIdx.y;
-  char* base = (char*)(is_v ? vc : kc) + layer * layer_stride_bytes + ((size_t)hh * smax + p0) * row_bytes + (size_t)idx * 16;
-  uint4 v[BEAM_MAX];
-  for (int b = 0; b < NB; ++b) v[b] = *reinterpret_cast<const uint4*>(base + b * slot_stride_bytes);
-  for (int j = 0; j < NB; ++j)
-    if (src[j] != j) *reinterpret_cast<uint4*>(base + j * slot_stride_bytes) = v[src[j]];
+  char* base0 = (char*)(is_v ? vc : kc) + layer * layer_stride_bytes + ((size_t)hh * smax + p0) * row_bytes;
+  int sj[BEAM_MAX];
+  for (int j = 0; j < NB; ++j) sj[j] = src[j];
+  // REORDER_CPT chunks per thread (fewer, fatter workgroups: most of a 2048-row grid used to exit at once)
+#pragma unroll
+  for (int c = 0; c < REORDER_CPT; ++c) {
+    const int idx = (blockIdx.x * REORDER_CPT + c) * 256 + threadIdx.x;
+    if (idx >= rows * cpr) break;
+    char* base = base0 + (size_t)idx * 16;
+    uint4 v[BEAM_MAX];
+    for (int b = 0; b < NB; ++b) v[b] = *reinterpret_cast<const uint4*>(base + b * slot_stride_bytes);
+    for (int j = 0; j < NB; ++j)
+      if (sj[j] != j) *reinterpret_cast<uint4*>(base + j * slot_stride_bytes) = v[sj[j]];
+  }
 }
 
 void launch_beam_step(ixtts_gpt* h, const SamplerState& s, hipStream_t st) {
@@ -405,7 +414,7 @@ void launch_beam_step(ixtts_gpt* h, const SamplerState& s, hipStream_t st) {
   const size_t layer_stride = (size_t)h->slots * slot_stride;
   // rows to move are bounded by the context bucket the graph is captured for (the host counts the steps it issues)
   const int max_rows = h->attn_bucket < NBKT ? std::min(h->smax, attn_cover(h->attn_bucket)) : h->smax;
-  dim3 grid(ceil_div(max_rows * (row_bytes / 16), 256), h->H, h->L * 2);
+  dim3 grid(ceil_div(max_rows * (row_bytes / 16), 256 * REORDER_CPT), h->H, h->L * 2);
   hipLaunchKernelGGL(beam_reorder_kv_kernel, grid, dim3(256), 0, st, h->kc, h->vc, (const int*)h->beam_src, (const int*)h->prompt_len,
                      (const int*)h->cur_len, (const int*)h->beam_done, h->num_beams, h->H, h->smax, layer_stride, slot_stride, row_bytes);
 }
