@@ -236,26 +236,56 @@ class IndexTTS2:
             req_emovec = self.cond.merge_emovec(sc, ec, ls, le, alpha=emo_alpha)
             req_cond32 = self.cond.get_conditioning(sc.transpose(1, 2), ls)[0]
             gpt_gen_time += time.perf_counter() - m0
-        for sent_ids in segments:
-            text_tokens = torch.as_tensor(sent_ids, dtype=torch.int32, device=self.device).reshape(-1)
-            m0 = time.perf_counter()
+        def conds_for_segment():
             emovec = req_emovec if req_emovec is not None else glue.merge_emovec(spk["spk_cond_emb"], emo_cond_emb, emo_alpha)
             if emo_vector is not None:
                 emovec = emovec_mat + (1 - weight_sum) * emovec
             cond32 = req_cond32 if req_cond32 is not None else glue.get_conditioning(spk["spk_cond_emb"])
             # inference_speech (model_v2.py:693-734)
-            conds_latent = torch.cat((cond32 + emovec.reshape(1, -1), self.speed_emb[1:2], self.speed_emb[0:1]), 0)
-            fake, embeds, mask = self._prepare_gpt_inputs(conds_latent, text_tokens)
-            self.gpt.store_mel_emb(embeds)
-            trunc = fake.shape[1]
-            out = self.gpt.generate(fake, bos_token_id=self.gpt_cfg["start_mel_token"], pad_token_id=self.stop_mel_token,
-                                    eos_token_id=self.stop_mel_token, attention_mask=mask, max_length=trunc + max_mel_tokens,
-                                    num_return_sequences=1, do_sample=True, top_p=top_p, top_k=top_k, temperature=temperature,
-                                    num_beams=num_beams, repetition_penalty=repetition_penalty, length_penalty=length_penalty,
-                                    **generation_kwargs)
-            codes = out[:, trunc:]
+            return torch.cat((cond32 + emovec.reshape(1, -1), self.speed_emb[1:2], self.speed_emb[0:1]), 0)
+
+        # Without beams the segments are independent sequences: decode them together, the weights are read once per step for
+        # all of them (the reference decodes segment after segment, infer_v2.py:616; tokens per segment are the same for
+        # greedy; with sampling each slot draws from its own counter-based stream).  Beam search keeps one segment at a time.
+        pre = None
+        if num_beams == 1 and len(segments) > 1 and not stream_return and not generation_kwargs.get("logits_processor"):
+            from .scheduler import DecodeScheduler, Segment
+
+            m0 = time.perf_counter()
+            greedy = top_k == 1
+            todo = []
+            for i, sent_ids in enumerate(segments):
+                tt = torch.as_tensor(sent_ids, dtype=torch.int32, device=self.device).reshape(-1)
+                cl = conds_for_segment()
+                fake, embeds, mask = self._prepare_gpt_inputs(cl, tt)
+                n_pad = int((mask == 0).sum().item())
+                max_new = max(0, min(max_mel_tokens, self.gpt.max_seq - fake.shape[1] - 2))
+                todo.append(Segment(0, i, embeds[0], n_pad, max_new, payload=cl))
+            pre = [None] * len(segments)
+            DecodeScheduler(self.gpt, self.gpt.max_batch, self.stop_mel_token).run(
+                todo, lambda seg, ids: pre.__setitem__(seg.index, (ids, seg.payload)), repetition_penalty=repetition_penalty,
+                temperature=temperature, top_k=top_k, top_p=top_p, do_sample=not greedy, seed=int(generation_kwargs.get("seed", 0)))
             torch.cuda.synchronize(self.device)
             gpt_gen_time += time.perf_counter() - m0
+        for seg_index, sent_ids in enumerate(segments):
+            text_tokens = torch.as_tensor(sent_ids, dtype=torch.int32, device=self.device).reshape(-1)
+            m0 = time.perf_counter()
+            if pre is not None:
+                ids, conds_latent = pre[seg_index]
+                codes = torch.from_numpy(np.asarray(ids).astype(np.int64)).reshape(1, -1).to(self.device)
+            else:
+                conds_latent = conds_for_segment()
+                fake, embeds, mask = self._prepare_gpt_inputs(conds_latent, text_tokens)
+                self.gpt.store_mel_emb(embeds)
+                trunc = fake.shape[1]
+                out = self.gpt.generate(fake, bos_token_id=self.gpt_cfg["start_mel_token"], pad_token_id=self.stop_mel_token,
+                                        eos_token_id=self.stop_mel_token, attention_mask=mask, max_length=trunc + max_mel_tokens,
+                                        num_return_sequences=1, do_sample=True, top_p=top_p, top_k=top_k, temperature=temperature,
+                                        num_beams=num_beams, repetition_penalty=repetition_penalty, length_penalty=length_penalty,
+                                        **generation_kwargs)
+                codes = out[:, trunc:]
+                torch.cuda.synchronize(self.device)
+                gpt_gen_time += time.perf_counter() - m0
             if not has_warned and bool((codes[:, -1] != self.stop_mel_token).any()):
                 warnings.warn(f"WARN: generation stopped due to exceeding `max_mel_tokens` ({max_mel_tokens}). "
                               f"Input text tokens: {text_tokens.shape[0]}. Consider reducing `max_text_tokens_per_segment`"
