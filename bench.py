@@ -58,9 +58,38 @@ def parse():
     ap.add_argument("--concurrency", type=int, default=1, help="requests in flight per GPU (config 3 style): their segments share the decode "
                     "slots through the continuous-batching scheduler (row N3); 1 = BASELINE config[1], the judged line")
     ap.add_argument("--no-cond", action="store_true", help="leave the conditioning encoders out of the timed region (feed a synthetic conds_latent)")
+    ap.add_argument("--decode", default="greedy", choices=["greedy", "beam"], help="greedy: BASELINE config[1] (the judged line); beam: the served "
+                    "default of config[2] -- 3-beam beam-sample, top_k 30, top_p 0.8, temperature 0.8 -- one segment at a time")
+    ap.add_argument("--bigvgan-only", action="store_true", help="BASELINE config[4]: 1000-frame random mel -> waveform microbench (20 warm-up + 100 timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
+
+
+def bigvgan_microbench(WR, dev, rank):
+    """BASELINE config[4] / SURVEY 8(d) config 5: mel ~ N(-4, 2) clipped to [-11.5, 2], fp32 [1, 80, 1000] -> [1, 1, 256000]."""
+    from voice_tts_amd.bigvgan import BigVGAN
+
+    m = BigVGAN(WR.BIGVGAN_CFG, max_frames=1024, device=dev).load_state_dict(WR.make_bigvgan_weights(WR.BIGVGAN_CFG, seed=1234))
+    F = 1000
+    mel = (torch.randn(1, 80, F, generator=torch.Generator().manual_seed(6)) * 2 - 4).clamp(-11.5, 2).to(dev)
+    for _ in range(20):
+        m(mel)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100):
+        m(mel)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 100
+    fl = m.flops(1, F)
+    alg_bytes = 732.8e6  # SURVEY 8(d): weights once + stage-boundary activations once + mel + wav, per 1000 frames
+    if rank == 0:
+        print(json.dumps({"metric": "bigvgan_ms_per_1000_frames", "value": round(ms, 3), "unit": "ms", "n_gpus": 1, "steps": 100, "warmup": 20,
+                          "higher_is_better": False, "dtype": "f32", "data": "synthetic", "audio_seconds_per_second": round(256 * F / 22050 / (ms * 1e-3), 1),
+                          "config": {"workload": "BigVGAN-only: 1000-frame random mel -> 256000 samples (11.61 s)"},
+                          "roofline": {"bound": "mfma", "achieved": round(fl / ms / 1e9, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / 157.3, 3),
+                                       "flops": fl, "hbm_GBps_algorithmic": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "hbm_peak_GBps": 8000.0}}), flush=True)
 
 
 def main():
@@ -81,12 +110,14 @@ def main():
     import voice_tts_amd.weights as WR
     from voice_tts_amd.pipeline import HotPath, audio_seconds
 
+    if args.bigvgan_only:
+        return bigvgan_microbench(WR, dev, rank)
     D = WR.GPT_CFG["model_dim"]
     n_seg, n_tok, n_codes = args.segments, args.tokens, args.codes
     frames = int(n_codes * 1.72)
     P = 34 + n_tok + 2 + 1
     R = max(1, args.concurrency)
-    hp = HotPath(dtype=args.dtype, device=dev, max_batch=4 if R > 1 else (max(2, n_seg) if n_seg <= 4 else 4), max_seq=P + n_codes + 64,
+    hp = HotPath(dtype=args.dtype, device=dev, max_batch=4 if R > 1 else (3 if args.decode == "beam" else (max(2, n_seg) if n_seg <= 4 else 4)), max_seq=P + n_codes + 64,
                  max_frames=frames)
 
     # ---- load: rank 0 builds the (synthetic, seeded) weights, RCCL broadcasts the packed arenas
@@ -149,6 +180,13 @@ def main():
         if R > 1:  # R requests in flight: all their segments go through the continuous-batching scheduler
             many = hp.generate_many([(e, p, n_codes) for _ in range(R) for (e, p) in prompts], fixed_length=True, repetition_penalty=10.0)
             codes = many[:n_seg]
+        elif args.decode == "beam":  # served default (infer_v2.py:598-606): beams of one segment occupy the slots, segments in turn
+            codes = []
+            for e, p in prompts:
+                hp.gpt.prefill(0, e, p)
+                hp.gpt.beam_begin(3)
+                hp.gpt.beam_decode(n_codes, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=True, seed=7)
+                codes.append(hp.gpt.beam_read(n_codes)[0][:n_codes])
         else:
             codes = hp.generate(prompts, n_codes, repetition_penalty=10.0, fixed_length=True)
         t1 = tick()
@@ -363,7 +401,9 @@ def main():
                 "workload": (f"1 /tts request per GPU: " if R == 1 else f"{R} concurrent /tts requests per GPU (segments share the decode slots, continuous batching B<=4), each ")
                             + f"{n_seg}x{n_tok}-token zh text segments (200-char utterance), "
                             + ("conditioning encoders on 249 prompt frames (conformer + perceiver, PyTorch-ROCm glue, fp32), " if use_cond else "")
-                            + f"greedy fixed-length decode {n_codes} codes/segment batched B={n_seg}, latent GPT forward, "
+                            + (f"greedy fixed-length decode {n_codes} codes/segment batched B={n_seg}, " if args.decode == "greedy" else
+                               f"3-beam beam-sample (top_k 30, top_p 0.8, T 0.8, theta 10) fixed-length decode {n_codes} codes/segment, segments in turn, ")
+                            + "latent GPT forward, "
                             + ("s2mel (length regulator + 25-step CFM/DiT, PyTorch-ROCm glue, fp32, 430-frame prompt), " if use_s2mel else "s2mel skipped (synthetic mel), ")
                             + f"BigVGAN {frames} frames/segment -> {audio_s:.2f} s audio; prompt feature extraction (w2v-bert, CAM++, semantic "
                             f"codec, reference mel) not built: spk_cond_emb / prompt_condition / ref_mel / style are synthetic HBM-resident inputs"

@@ -1,2 +1,2 @@
-timeout -k 10 900 python -m pytest tests/test_gpu_gpt.py tests/test_gpu_infer_v2.py -m gpu -x -q > gpurun_out/t.log 2>&1; tail -3 gpurun_out/t.log
-python tools/beam_perf.py 2>&1 | grep beam
+timeout -k 10 600 python bench.py --bigvgan-only 2>/dev/null | tail -1
+timeout -k 10 900 python bench.py --decode beam --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/bench_beam.json 2> gpurun_out/bench_beam.err; tail -2 gpurun_out/bench_beam.err; cut -c1-260 gpurun_out/bench_beam.json; grep -o "stage_ms_per_step[^}]*}" gpurun_out/bench_beam.json
