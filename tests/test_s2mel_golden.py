@@ -77,3 +77,24 @@ def test_wavenet_gemm_form_equals_the_conv_form():
     want = m._wavenet(x.clone(), torch.ones(2, 1, 37), t2, True)
     got = m._wavenet_gemm(x.clone(), t2) + m.wn_out_bias[None, :, None]
     assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+
+
+def test_dit_head_on_the_needed_frames_only():
+    """dit_step(out_from=k) -- the WaveNet head evaluated on frames [k - receptive field, T) -- equals the full evaluation on
+    frames [k, T): what the CFM solver uses, since it zeroes the prompt frames after every step."""
+    import voice_tts_amd.s2mel as S2
+
+    cfg = S2.tiny_s2mel_cfg()
+    m = S2.S2Mel(S2.make_s2mel_weights(cfg, seed=21), cfg, "cpu")
+    g = torch.Generator().manual_seed(22)
+    B, T, k = 2, 61, 27
+    x = torch.randn(1, 80, T, generator=g)
+    prompt_x = torch.randn(B, 80, T, generator=g)
+    cond = torch.randn(B, T, cfg["content_dim"], generator=g)
+    style = torch.randn(B, cfg["style_dim"], generator=g)
+    ctx = m.dit_prepare(prompt_x, torch.tensor([T, T]), style, cond)
+    t = torch.tensor([0.3, 0.3])
+    full = m.dit_step(ctx, x, t)
+    part = m.dit_step(ctx, x, t, out_from=k)
+    assert part.shape == (B, 80, T - k)
+    assert (part - full[:, :, k:]).abs().max().item() <= 1e-5 * max(1.0, full.abs().max().item())

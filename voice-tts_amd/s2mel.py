@@ -453,28 +453,39 @@ class S2Mel:
                 attn_mask = attn_mask.expand(B, 1, T, T)
         return dict(B=B, T=T, base=base, x_mask=x_mask.to(base.dtype), attn_mask=attn_mask, full=full)
 
-    def dit_step(self, ctx, x, t):
+    def dit_step(self, ctx, x, t, out_from=0):
         """The (x, t)-dependent part of DiT.forward (diffusion_transformer.py:186-257).  x [B,80,T] or [1,80,T] shared by
-        the whole batch (the CFG stack feeds the same x to both branches); t [B]."""
-        W = self.W
+        the whole batch (the CFG stack feeds the same x to both branches); t [B].
+
+        out_from > 0: the caller only uses frames [out_from, T) of the result (the CFM solver zeroes the prompt frames of x
+        after every step).  After the transformer nothing mixes frames except the WaveNet's k-tap convs, so the head runs on
+        frames [out_from - halo, T) only, halo = the WaveNet's receptive field; the returned tensor covers [out_from, T) and
+        equals the full computation there."""
+        W, cfg = self.W, self.cfg
         e = "cfm.estimator."
         B, T, base = ctx["B"], ctx["T"], ctx["base"]
-        Hw = self.cfg["wavenet_hidden"]
         xt = x.transpose(1, 2)  # [Bx,T,80]
         t1 = self._t_embed(t, e + "t_embedder")
         x_in = base + F.linear(xt, self.merge_x)  # broadcasts a shared x over the batch
         x_res = self._transformer(x_in, t1, ctx["attn_mask"])
+        halo = sum((cfg["wavenet_kernel"] - 1) * cfg["wavenet_dilation_rate"] ** i for i in range(cfg["wavenet_layers"])) // 2 + 1
+        lo = max(0, out_from - halo) if (ctx["full"] and out_from > 0) else 0
+        if lo > 0:
+            x_res, xt = x_res[:, lo:], xt[:, lo:]
+        Th = T - lo
         x_res = F.linear(x_res, self.skipl_res, W[e + "skip_linear.bias"]) + F.linear(xt, self.skipl_x)
         h = _lin(x_res, W, e + "conv1").transpose(1, 2)
         t2 = self._t_embed(t, e + "t_embedder2")
-        if h.is_cuda and ctx["full"] and T > 2 * self.cfg["wavenet_kernel"] * self.cfg["wavenet_dilation_rate"] ** (self.cfg["wavenet_layers"] - 1):
+        if h.is_cuda and ctx["full"] and Th > 2 * cfg["wavenet_kernel"] * cfg["wavenet_dilation_rate"] ** (cfg["wavenet_layers"] - 1):
             h = self._wavenet_gemm(h, t2).transpose(1, 2) + F.linear(x_res, W[e + "res_projection.weight"], W[e + "res_projection.bias"] + self.wn_out_bias)
         else:
-            h = self._wavenet(h, ctx["x_mask"], t2, ctx["full"]).transpose(1, 2) + _lin(x_res, W, e + "res_projection")
+            mask = ctx["x_mask"][:, :, lo:] if lo > 0 else ctx["x_mask"]
+            h = self._wavenet(h, mask, t2, ctx["full"]).transpose(1, 2) + _lin(x_res, W, e + "res_projection")
         ss = _lin(F.silu(t1), W, e + "final_layer.adaLN_modulation.1")
         h = ln_modulate(h, ss)
         h = _lin(h, W, e + "final_layer.linear").transpose(1, 2)
-        return F.conv1d(h, W[e + "conv2.weight"], W[e + "conv2.bias"])
+        out = F.conv1d(h, W[e + "conv2.weight"], W[e + "conv2.bias"])
+        return out[:, :, out_from - lo:] if out_from > 0 else out
 
     def dit(self, x, prompt_x, x_lens, t, style, cond):
         """DiT.forward, eval mode.  x, prompt_x [B,80,T]; cond [B,T,content]."""
@@ -500,14 +511,19 @@ class S2Mel:
         else:
             ctx = self.dit_prepare(prompt_x, x_lens, style, mu)
         t = t_span[0]
+        # the prompt frames of x are reset to zero after every step (flow_matching.py:112): the velocity there is never used
+        skip = Tp if ctx["full"] else 0
         for step in range(1, len(t_span)):
             dt = t_span[step] - t_span[step - 1]
             if inference_cfg_rate > 0:
-                d = self.dit_step(ctx, x, torch.stack([t, t]))
+                d = self.dit_step(ctx, x, torch.stack([t, t]), out_from=skip)
                 dphi = (1.0 + inference_cfg_rate) * d[0:1] - inference_cfg_rate * d[1:2]
             else:
-                dphi = self.dit_step(ctx, x, t.expand(B))
-            x = x + dt * dphi
+                dphi = self.dit_step(ctx, x, t.expand(B), out_from=skip)
+            if skip > 0:
+                x[:, :, skip:] += dt * dphi
+            else:
+                x = x + dt * dphi
             t = t + dt
             x[:, :, :Tp] = 0
         return x
