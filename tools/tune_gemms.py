@@ -1,5 +1,6 @@
 """Record the TunableOp results file the s2mel glue ships (voice-tts_amd/tunable/gfx950_s2mel.csv): one pass of the stage at
-the bench's production shape with tuning on.  Run on the GPU box:  python tools/tune_gemms.py gpurun_out/gfx950_s2mel.csv"""
+the bench's production shape with tuning on.  (Only the DiT's shapes: tuning the conditioning encoders' 124 x 512 x 261632
+subsampling GEMM made one candidate solution fault the GPU -- do not add exotic shapes without a reason.)  Run on the GPU box:  python tools/tune_gemms.py gpurun_out/gfx950_s2mel.csv"""
 import os
 import sys
 
