@@ -160,6 +160,9 @@ typedef struct ixtts_sampler_cfg {
   int do_sample;            /* 0: argmax of penalised logits; 1: multinomial after warpers   */
   int suppress_stop;        /* bench-only fixed-length mode: stop token forced to -inf       */
   uint64_t seed;            /* Philox seed for do_sample (cannot match torch's CPU stream)   */
+  float typical_mass;       /* > 0: the custom TypicalLogitsWarper of `inference_speech(typical_sampling=True, typical_mass=...)`
+                               (model_v2.py:717-722, utils/typical_sampling.py) after the repetition penalty; 0: off */
+  int reserved;
 } ixtts_sampler_cfg;
 
 typedef struct ixtts_gpt ixtts_gpt;

@@ -197,8 +197,26 @@ def top_p_filter(scores, top_p, min_keep=1):
     return scores.masked_fill(remove, float("-inf"))
 
 
-def process_logits(logits, history, theta=10.0, temperature=None, top_k=None, top_p=None, min_keep=1, suppress=None):
-    """Processor chain in `_get_logits_processor` order (generation_utils.py:900-901,1020-1044).
+def typical_filter(scores, mass=0.9, min_keep=1):
+    """indextts/utils/typical_sampling.py:8-30 (the custom processor `inference_speech(typical_sampling=True)` appends,
+    model_v2.py:717-722): keep the tokens whose surprise -log p is closest to the entropy until their mass reaches `mass`."""
+    normalized = torch.log_softmax(scores, dim=-1)
+    p = torch.exp(normalized)
+    ent = -(normalized * p).nansum(-1, keepdim=True)
+    shifted = torch.abs((-normalized) - ent)
+    sorted_scores, sorted_idx = torch.sort(shifted, descending=False)
+    cum = scores.gather(-1, sorted_idx).softmax(dim=-1).cumsum(dim=-1)
+    last = int((cum < mass).sum())
+    remove_sorted = sorted_scores > sorted_scores[min(last, sorted_scores.numel() - 1)]
+    if min_keep > 1:
+        remove_sorted[:min_keep] = False
+    remove = torch.zeros_like(remove_sorted).scatter(0, sorted_idx, remove_sorted)
+    return scores.masked_fill(remove, float("-inf"))
+
+
+def process_logits(logits, history, theta=10.0, temperature=None, top_k=None, top_p=None, min_keep=1, suppress=None, typical_mass=None):
+    """Processor chain in `_get_logits_processor` order (generation_utils.py:900-901,1020-1044); a custom processor
+    (typical sampling) sits between the repetition penalty and the warpers.
 
     `suppress` (bench-only fixed-length mode): ids forced to -inf first.
     """
@@ -207,6 +225,8 @@ def process_logits(logits, history, theta=10.0, temperature=None, top_k=None, to
         s[torch.as_tensor(suppress, dtype=torch.long)] = float("-inf")
     if theta is not None and theta != 1.0:
         s = repetition_penalty(s, history, theta)
+    if typical_mass is not None:
+        s = typical_filter(s, typical_mass, min_keep)
     if temperature is not None and temperature != 1.0:
         s = s / temperature
     if top_k is not None and top_k > 0:

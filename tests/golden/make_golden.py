@@ -436,6 +436,14 @@ def gen_sampler():
         out[f"{case}_pen"] = s1[0]
         out[f"{case}_final"] = s4[0]
         out[f"{case}_probs"] = torch.softmax(s4[0], -1)
+        # the same chain with the reference's custom typical-sampling processor after the penalty (model_v2.py:717-722)
+        from indextts.utils.typical_sampling import TypicalLogitsWarper
+        for mass in (0.9, 0.3):
+            t1 = TypicalLogitsWarper(mass=mass, min_tokens_to_keep=min_keep)(hist, s1.clone())
+            t4 = TopPLogitsWarper(0.8, min_tokens_to_keep=min_keep)(hist, TopKLogitsWarper(30, min_tokens_to_keep=min_keep)(hist, TemperatureLogitsWarper(0.8)(hist, t1.clone())))
+            tag = f"{case}_typ{int(mass * 100)}"
+            out[tag + "_kept"] = torch.isfinite(t1[0])
+            out[tag + "_probs"] = torch.softmax(t4[0], -1)
     save("sampler_kat.npz", **out)
 
 

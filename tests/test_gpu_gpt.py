@@ -172,6 +172,53 @@ def test_sampling_distribution_vs_oracle(tiny_f32):
             assert len(counts) > 1 or ref[top] > 0.97
 
 
+def test_typical_sampling_on_device_vs_oracle(tiny_f32):
+    """`inference_speech(typical_sampling=True, typical_mass=m)` (model_v2.py:717-722): the TypicalLogitsWarper runs inside the
+    sampler kernel between the repetition penalty and the warpers; the processed probability vector matches the oracle
+    (itself pinned to the reference's class), for sampling and for the greedy argmax."""
+    from oracle import gpt as OG
+
+    g, cfg, W, orc, eng = tiny_f32
+    embeds = torch.from_numpy(g["embeds_plain"])
+    P = len(g["mask_plain"])
+    forced = [11, 4097, 256]
+
+    def replay():
+        eng.prefill(0, embeds, 0)
+        for tok in forced:
+            eng.force_next(0, tok)
+            eng.decode(1, 1, repetition_penalty=10.0)
+
+    replay()
+    logits = torch.from_numpy(eng.read_logits(0))
+    hist = [1] * (P - 1) + [8192] + forced
+    for mass in (0.9, 0.5, 0.2):
+        ref = torch.softmax(OG.process_logits(logits, hist, 10.0, 0.8, 30, 0.8, 1, typical_mass=mass), -1).numpy()
+        replay()
+        eng.decode(1, 1, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, do_sample=True, seed=5, typical_mass=mass)
+        probs = eng.read_probs(0)
+        assert (probs > 0).sum() == (ref > 0).sum(), (mass, (probs > 0).sum(), (ref > 0).sum())
+        assert np.abs(probs - ref).max() <= 1e-5, (mass, np.abs(probs - ref).max())
+        assert ref[int(eng.read(0)[0][len(forced)])] > 0
+        # greedy through the same processor: argmax of the typical-filtered scores
+        replay()
+        eng.decode(1, 1, repetition_penalty=10.0, typical_mass=mass)
+        want = int(torch.argmax(OG.process_logits(logits, hist, 10.0, typical_mass=mass)))
+        assert int(eng.read(0)[0][len(forced)]) == want
+
+
+def test_typical_sampling_with_beams_runs(tiny_f32):
+    g, cfg, W, orc, eng3 = tiny_f32
+    from voice_tts_amd.gpt_engine import GptEngine
+
+    eng = GptEngine(cfg, dtype="f32", max_seq=256, max_batch=3, device=eng3.device).load_state_dict(W)
+    eng.prefill(0, torch.from_numpy(g["embeds_plain"]), 0)
+    eng.beam_begin(3)
+    eng.beam_decode(12, typical_mass=0.9, suppress_stop=True, seed=3)
+    ids = eng.beam_read(12)[0]
+    assert len(ids) == 12 and int(ids.max()) < 8194 and int(ids.min()) >= 0
+
+
 def test_latent_pass_vs_reference(tiny_f32, dev):
     g, cfg, W, orc, eng = tiny_f32
     conds = torch.from_numpy(g["conds_latent"])

@@ -134,6 +134,21 @@ def test_sampler_processors_vs_hf(golden, case, min_keep):
     assert int(keep.sum()) >= min_keep
 
 
+@pytest.mark.parametrize("case,min_keep", [("sample", 1), ("beam", 2)])
+@pytest.mark.parametrize("mass", [0.9, 0.3])
+def test_typical_sampling_vs_reference_processor(golden, case, min_keep, mass):
+    """The custom typical-sampling processor (utils/typical_sampling.py, model_v2.py:717-722) in the chain, against the
+    reference's own class: same surviving set after it, same final probabilities."""
+    g = golden("sampler_kat.npz")
+    s_in = torch.from_numpy(g[f"{case}_in"])
+    hist = g[f"{case}_hist"].tolist()
+    tag = f"{case}_typ{int(mass * 100)}"
+    kept = torch.isfinite(OG.typical_filter(OG.repetition_penalty(s_in, hist, 10.0), mass, min_keep))
+    assert torch.equal(kept, torch.from_numpy(g[tag + "_kept"]))
+    fin = OG.process_logits(s_in, hist, 10.0, 0.8, 30, 0.8, min_keep, typical_mass=mass)
+    assert torch.allclose(torch.softmax(fin, -1), torch.from_numpy(g[tag + "_probs"]), atol=1e-6)
+
+
 @pytest.mark.parametrize("tag", ["noeos", "mid", "mid2", "eos", "eos2"])
 def test_beam_sample_vs_reference_scorer(golden, tag):
     """3-beam beam-sample (the served default): oracle loop + scorer restatement vs a trace produced by

@@ -37,25 +37,6 @@ struct BeamArgs {
   int NB;
 };
 
-__device__ __forceinline__ float block_max_1024(float v, float* red) {
-  v = wave_max(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float m = red[0];
-  for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
-  return m;
-}
-__device__ __forceinline__ float block_sum_1024(float v, float* red) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float s = 0.f;
-  for (int i = 0; i < 16; ++i) s += red[i];
-  return s;
-}
-
 // Phase A, one workgroup per beam: log_softmax -> penalty -> temperature -> TopK (min keep 2) -> TopP (min keep 2); the
 // survivors go to global memory sorted by score.  (As one workgroup looping over the beams, with the TopP sums on one
 // thread, the whole step took 164 us at 3 beams.)
@@ -108,10 +89,15 @@ __global__ __launch_bounds__(1024) void beam_cand_kernel(BeamArgs a) {
         x = vals[i] - lse;  // log_softmax
         if (cfg.suppress_stop && v == s.stop) x = -INFINITY;
         if (sn[i] && theta != 1.0f) x = (x < 0.f) ? x * theta : x / theta;
-        x *= inv_t;
       }
       vals[i] = x;
     }
+    if (cfg.typical_mass > 0.f) {  // custom processor: after the penalty, before the warpers; min_tokens_to_keep = 2 with beams
+      __shared__ TypicalScratch typ;
+      typical_filter_1024<SAMP_PT>(vals, V, cfg.typical_mass, 2, typ);
+    }
+#pragma unroll
+    for (int i = 0; i < SAMP_PT; ++i) vals[i] *= inv_t;
     const int k = min(max(cfg.top_k, 2), SAMP_MAXK);
     if (threadIdx.x == 0) {
       sel_prefix = 0u;

@@ -957,6 +957,126 @@ __device__ __forceinline__ void radix_pick_bin(const unsigned int* hist, unsigne
   __syncthreads();
 }
 
+// ---- block helpers of the 1024-thread sampler kernels
+__device__ __forceinline__ float block_max_1024(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float m = red[0];
+  for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+  return m;
+}
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += red[i];
+  return s;
+}
+
+// TypicalLogitsWarper (indextts/utils/typical_sampling.py:8-30): keep the tokens whose surprise -log p is closest to the
+// entropy, in that order, until their probability mass reaches `mass` (ties with the last one kept), at least `min_keep`.
+// scores: this thread's PT values of the V-vector (index threadIdx.x + i*1024), -inf = already removed; filtered in place.
+// The threshold is the exact key at which the cumulative mass first reaches `mass`: a 4-pass radix select over the key
+// bits with per-bin MASS histograms in 2^-48 fixed point (integer atomics: the result does not depend on their order).
+struct TypicalScratch {
+  float red[16];
+  unsigned long long mhist[256], wtot[4], rem;
+  unsigned int prefix, nkept, kmin;
+};
+
+template <int PT>
+__device__ __forceinline__ void typical_filter_1024(float (&scores)[PT], int V, float mass, int min_keep, TypicalScratch& sc) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) mx = fmaxf(mx, scores[i]);
+  mx = block_max_1024(mx, sc.red);
+  float se = 0.f;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) se += (scores[i] > -INFINITY) ? expf(scores[i] - mx) : 0.f;
+  const float lse = mx + logf(block_sum_1024(se, sc.red));
+  float p[PT], nrm[PT];
+  float e = 0.f;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    nrm[i] = scores[i] - lse;
+    p[i] = (scores[i] > -INFINITY) ? expf(nrm[i]) : 0.f;
+    if (p[i] > 0.f) e -= p[i] * nrm[i];  // nansum: 0 * -inf terms are skipped
+  }
+  const float ent = block_sum_1024(e, sc.red);
+  unsigned int key[PT];
+  unsigned long long pm[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    key[i] = (scores[i] > -INFINITY) ? __float_as_uint(fabsf(-nrm[i] - ent)) : 0x7f800000u;  // non-negative floats order as their bits
+    pm[i] = (unsigned long long)(p[i] * 281474976710656.0f);
+  }
+  if (t == 0) {
+    sc.prefix = 0u;
+    sc.rem = (unsigned long long)((double)mass * 281474976710656.0);
+  }
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (t < 256) sc.mhist[t] = 0ull;
+    __syncthreads();
+    const unsigned int prefix = sc.prefix;
+    const unsigned long long rem = sc.rem;
+    const unsigned int pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+      if (t + i * 1024 < V && pm[i] > 0ull && (key[i] & pmask) == prefix) atomicAdd(&sc.mhist[(key[i] >> shift) & 0xffu], pm[i]);
+    __syncthreads();
+    // the lowest bin at which the running mass reaches `rem`, by 256 threads (inclusive prefix sums, ascending)
+    unsigned long long x = t < 256 ? sc.mhist[t] : 0ull, pre = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned int lo = __shfl_up((unsigned int)pre, o, 64), hi = __shfl_up((unsigned int)(pre >> 32), o, 64);
+      if (lane >= o) pre += ((unsigned long long)hi << 32) | lo;
+    }
+    if (t < 256 && lane == 63) sc.wtot[w] = pre;
+    __syncthreads();
+    if (t < 256) {
+      unsigned long long below = 0ull;
+      for (int ww = 0; ww < w; ++ww) below += sc.wtot[ww];
+      const unsigned long long P = pre + below, Pprev = P - x;
+      const bool last_nonempty = (t == 255);  // (a total short of `rem` by rounding: take the top bin)
+      if ((Pprev < rem && P >= rem) || (last_nonempty && P < rem)) {
+        sc.prefix = prefix | ((unsigned int)t << shift);
+        sc.rem = rem - Pprev;
+      }
+    }
+    __syncthreads();
+  }
+  const unsigned int tau = sc.prefix;
+  // min_tokens_to_keep: the `min_keep` smallest keys stay whatever the threshold (only matters when fewer survive)
+  if (t == 0) {
+    sc.nkept = 0u;
+    sc.kmin = 0xffffffffu;
+  }
+  __syncthreads();
+  unsigned int mine = 0u;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) mine += (t + i * 1024 < V && key[i] <= tau) ? 1u : 0u;
+  if (mine) atomicAdd(&sc.nkept, mine);
+  __syncthreads();
+  unsigned int tau2 = tau;
+  if ((int)sc.nkept < min_keep) {  // workgroup-uniform
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+      if (t + i * 1024 < V && key[i] > tau) atomicMin(&sc.kmin, key[i]);
+    __syncthreads();
+    tau2 = sc.kmin;
+  }
+#pragma unroll
+  for (int i = 0; i < PT; ++i)
+    if (!(key[i] <= tau || key[i] == tau2)) scores[i] = -INFINITY;
+  __syncthreads();
+}
+
 constexpr int SAMP_MAXK = 128;  // top_k supported on the device
 constexpr int SAMP_PT = 9;      // logits per thread (V <= 9216)
 
@@ -1001,8 +1121,6 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerState s) {
   const float inv_t = (sampling && cfg.temperature > 0.f) ? 1.0f / cfg.temperature : 1.0f;
 
   float vals[SAMP_PT];
-  float best = -INFINITY;
-  int besti = 0x7fffffff;
 #pragma unroll
   for (int i = 0; i < SAMP_PT; ++i) {
     const int v = threadIdx.x + i * 1024;
@@ -1011,13 +1129,25 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerState s) {
       x = raw[i];
       if (cfg.suppress_stop && v == s.stop) x = -INFINITY;
       if (sn[i] && theta != 1.0f) x = (x < 0.f) ? x * theta : x / theta;  // RepetitionPenaltyLogitsProcessor
-      if (sampling) x = x * inv_t;                                        // TemperatureLogitsWarper (x / T)
-      if (x > best || (x == best && v < besti)) {
-        best = x;
+    }
+    vals[i] = x;
+  }
+  if (cfg.typical_mass > 0.f) {  // custom processor of inference_speech(typical_sampling=True): after the penalty, before the warpers
+    __shared__ TypicalScratch typ;
+    typical_filter_1024<SAMP_PT>(vals, s.V, cfg.typical_mass, 1, typ);
+  }
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < SAMP_PT; ++i) {
+    const int v = threadIdx.x + i * 1024;
+    if (v < s.V) {
+      if (sampling) vals[i] = vals[i] * inv_t;  // TemperatureLogitsWarper (x / T)
+      if (vals[i] > best || (vals[i] == best && v < besti)) {
+        best = vals[i];
         besti = v;
       }
     }
-    vals[i] = x;
   }
   // block argmax with lowest-index tie break (torch.argmax returns the first maximal element)
 #pragma unroll

@@ -86,8 +86,8 @@ class GptEngine:
         self._keep = e  # keep alive until the stream has consumed it
 
     def decode(self, n_active, n_steps, repetition_penalty=10.0, temperature=1.0, top_k=0, top_p=1.0,
-               do_sample=False, suppress_stop=False, seed=0):
-        sc = _lib.SamplerCfg(repetition_penalty, temperature, top_k, top_p, int(do_sample), int(suppress_stop), seed)
+               do_sample=False, suppress_stop=False, seed=0, typical_mass=0.0):
+        sc = _lib.SamplerCfg(repetition_penalty, temperature, top_k, top_p, int(do_sample), int(suppress_stop), seed, float(typical_mass), 0)
         with torch.cuda.device(self.device):
             rc = _lib.lib().ixtts_gpt_decode(self._h, n_active, n_steps, C.byref(sc), self._stream())
         _lib.check(rc, "ixtts_gpt_decode")
@@ -122,8 +122,8 @@ class GptEngine:
             _lib.check(_lib.lib().ixtts_gpt_beam_begin(self._h, int(num_beams), self._stream()), "ixtts_gpt_beam_begin")
         self._nb = int(num_beams)
 
-    def beam_decode(self, n_steps, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=False, seed=0):
-        sc = _lib.SamplerCfg(repetition_penalty, temperature, top_k, top_p, 1, int(suppress_stop), seed)
+    def beam_decode(self, n_steps, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=False, seed=0, typical_mass=0.0):
+        sc = _lib.SamplerCfg(repetition_penalty, temperature, top_k, top_p, 1, int(suppress_stop), seed, float(typical_mass), 0)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().ixtts_gpt_beam_decode(self._h, n_steps, C.byref(sc), self._stream()), "ixtts_gpt_beam_decode")
 
@@ -181,8 +181,14 @@ class GptEngine:
             raise RuntimeError("generate(): call store_mel_emb first (model_v2.py:137)")
         if num_beams != 1 and (num_beams > self.max_batch or not do_sample or length_penalty != 0.0):
             raise NotImplementedError("beam mode needs max_batch >= num_beams, do_sample=True and length_penalty=0.0 (the served configuration)")
-        if logits_processor is not None and len(logits_processor) > 0:
-            raise NotImplementedError("custom logits processors (typical sampling) are not implemented in the HIP engine")
+        # the one custom processor inference_speech ever builds is TypicalLogitsWarper(mass=typical_mass) (model_v2.py:717-722):
+        # it runs on the device; anything else has no kernel
+        typical_mass = float(unused.pop("typical_mass", 0.0)) if unused.pop("typical_sampling", False) else 0.0
+        for proc in (logits_processor or []):
+            if type(proc).__name__ == "TypicalLogitsWarper" and hasattr(proc, "mass"):
+                typical_mass = float(proc.mass)
+            else:
+                raise NotImplementedError(f"logits processor {type(proc).__name__} has no device implementation (only typical sampling does)")
         if inputs.shape[0] != 1 or num_return_sequences != 1:
             raise NotImplementedError("one sequence per generate() call (autoregressive_batch_size = 1, infer_v2.py:602)")
         greedy = (not do_sample) or top_k == 1
@@ -208,7 +214,7 @@ class GptEngine:
             while done_steps < max_new and not fin:
                 n = min(sync_every, max_new - done_steps)
                 self.beam_decode(n, repetition_penalty=repetition_penalty, temperature=temperature, top_k=top_k, top_p=top_p,
-                                 suppress_stop=suppress_stop, seed=int(unused.get("seed", 0)))
+                                 suppress_stop=suppress_stop, seed=int(unused.get("seed", 0)), typical_mass=typical_mass)
                 done_steps += n
                 ids, fin = self.beam_read(max_new)[:2]
             out = torch.cat([inputs.reshape(1, -1).to(torch.long).cpu(), torch.from_numpy(ids.astype(np.int64)).reshape(1, -1)], dim=1)
@@ -218,7 +224,7 @@ class GptEngine:
         while done < max_new and not fin:
             n = min(sync_every, max_new - done)
             self.decode(1, n, repetition_penalty=repetition_penalty, temperature=temperature, top_k=top_k, top_p=top_p,
-                        do_sample=not greedy, suppress_stop=suppress_stop, seed=int(unused.get("seed", 0)))
+                        do_sample=not greedy, suppress_stop=suppress_stop, seed=int(unused.get("seed", 0)), typical_mass=typical_mass)
             done += n
             ids, fin = self.read(0)
         ids = ids[:max_new]

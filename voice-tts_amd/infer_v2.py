@@ -264,7 +264,8 @@ class IndexTTS2:
             pre = [None] * len(segments)
             DecodeScheduler(self.gpt, self.gpt.max_batch, self.stop_mel_token).run(
                 todo, lambda seg, ids: pre.__setitem__(seg.index, (ids, seg.payload)), repetition_penalty=repetition_penalty,
-                temperature=temperature, top_k=top_k, top_p=top_p, do_sample=not greedy, seed=int(generation_kwargs.get("seed", 0)))
+                temperature=temperature, top_k=top_k, top_p=top_p, do_sample=not greedy, seed=int(generation_kwargs.get("seed", 0)),
+                typical_mass=float(generation_kwargs.get("typical_mass", 0.9)) if generation_kwargs.get("typical_sampling") else 0.0)
             torch.cuda.synchronize(self.device)
             gpt_gen_time += time.perf_counter() - m0
         for seg_index, sent_ids in enumerate(segments):
