@@ -447,8 +447,97 @@ def gen_sampler():
     save("sampler_kat.npz", **out)
 
 
+FRONT_TEXTS = [
+    # inputs from the reference's own case list (front.py:440-489) that need no number verbaliser, plus a few of ours
+    "晕XUAN4是一种GAN3觉", "我爱你！", "I love you!", "“我爱你”的英语是“I love you”", "受不liao3你了",
+    "“衣裳”不读衣chang2，而是读衣shang5", "最zhong4要的是：不要chong2蹈覆辙", "不zuo1死就不会死", "这酒...里...有毒...",
+    "只有,,,才是最好的", "只有，，，才是最好的", "用beta1测试", "have you ever been to beta2?", "where's the money?", "who's there?",
+    "which's the best?", "how's it going?", "今天是个好日子 it's a good day",
+    "约瑟夫·高登-莱维特（Joseph Gordon-Levitt is an American actor）",
+    "蒂莫西·唐纳德·库克（英文名：Timothy Donald Cook），通称蒂姆·库克（Tim Cook），美国商业经理、工业工程师和工业开发商，现任苹果公司首席执行官。",
+    "《盗梦空间》是由美国华纳兄弟影片公司出品的电影，由克里斯托弗·诺兰执导并编剧，莱昂纳多·迪卡普里奥、玛丽昂·歌迪亚等联袂主演。",
+    "ju4 que4 xün1 lüe4 nv3 是拼音", "someone@example.com", "such as XTTS, CosyVoice, Fish-Speech, and F-TTS", "ta shuo: “ni hao3 ma5？”\n我说：好！  ",
+    "price is $5 (five) ~ [six]; 「seven」—eight", "here's what she's saying: that's it", "",
+]
+
+
+def gen_front():
+    """Text front-end: the reference's TextNormalizer (identity objects in place of the absent WeText verbalisers),
+    its CJK helpers, TextTokenizer on a small sentencepiece model trained here, and its segment splitter on seeded
+    random token streams (front.py:11-436, common.py:29-82)."""
+    import json
+    import random
+    import warnings
+
+    import sentencepiece as spm
+    from indextts.utils.common import de_tokenized_by_CJK_char, tokenize_by_CJK_char
+    from indextts.utils.front import TextNormalizer, TextTokenizer
+
+    class Identity:
+        def normalize(self, text):
+            return text
+
+    norm = TextNormalizer()
+    norm.zh_normalizer, norm.en_normalizer = Identity(), Identity()
+    out = {"normalize": [], "cjk": [], "pinyin": [], "tokenizer": [], "split": []}
+    for t in FRONT_TEXTS:
+        out["normalize"].append({"text": t, "use_chinese": norm.use_chinese(t), "normalized": norm.normalize(t)})
+        spaced = tokenize_by_CJK_char(t)
+        out["cjk"].append({"text": t, "spaced": spaced, "spaced_keep_case": tokenize_by_CJK_char(t, do_upper_case=False),
+                           "joined": de_tokenized_by_CJK_char(spaced), "joined_lower": de_tokenized_by_CJK_char(spaced, do_lower_case=True)})
+    for p in ["ju4", "que2", "xün1", "xuan4", "Juan3", "lü4", "zhong1", "QU5", "jue2", "xu1"]:
+        out["pinyin"].append({"pinyin": p, "corrected": norm.correct_pinyin(p)})
+
+    # a small BPE model of our own over the normalised, CJK-spaced, upper-cased case texts
+    model_prefix = os.path.join(HERE, "tiny_bpe")
+    corpus = os.path.join(HERE, "_tiny_bpe_corpus.txt")
+    with open(corpus, "w", encoding="utf-8") as f:
+        for rep in range(4):
+            for t in FRONT_TEXTS:
+                if t:
+                    f.write(tokenize_by_CJK_char(norm.normalize(t)) + "\n")
+    spm.SentencePieceTrainer.train(input=corpus, model_prefix=model_prefix, vocab_size=330, model_type="bpe", character_coverage=1.0,
+                                   bos_id=0, eos_id=1, unk_id=2, pad_id=-1, user_defined_symbols=["XUAN4", "GAN3", "ZHONG4", "JV4"],
+                                   normalization_rule_name="identity", minloglevel=2)
+    os.remove(corpus)
+    os.remove(model_prefix + ".vocab")
+    tok = TextTokenizer(model_prefix + ".model", norm)
+    out["tokenizer_meta"] = {"vocab_size": tok.vocab_size, "unk_token_id": tok.unk_token_id, "special_tokens_map": tok.special_tokens_map,
+                             "punct_ids": tok.convert_tokens_to_ids(list(TextTokenizer.punctuation_marks_tokens))}
+    for t in FRONT_TEXTS + ["好", " a ", "未登录字符：龘"]:
+        ids = tok.encode(t)
+        toks = tok.tokenize(t)
+        out["tokenizer"].append({"text": t, "ids": ids, "tokens": toks, "decoded": tok.decode(ids) if ids else "",
+                                 "decoded_lower": tok.decode(ids, do_lower_case=True) if ids else "",
+                                 "segments_20": tok.split_segments(toks, 20), "segments_120": tok.split_segments(toks)})
+    out["tokenizer_batch"] = tok.batch_encode([t for t in FRONT_TEXTS if t][:6])
+
+    rng = random.Random(20251128)
+    words = ["▁A", "B", "▁CD", "你", "好", "▁E", "F", "世", "界", "▁XUAN4"]
+    marks = [".", "!", "?", "▁.", "▁?", "▁...", ",", "▁,", "-", "'", "▁'", "…"]
+    for case in range(400):
+        n = rng.choice([0, 1, 2, 3, 7, 15, 40, 90, 200])
+        p_mark = rng.choice([0.02, 0.08, 0.2, 0.4])
+        toks = [rng.choice(marks) if rng.random() < p_mark else rng.choice(words) for _ in range(n)]
+        limit = rng.choice([4, 8, 20, 50, 120])
+        quick = rng.choice([0, 0, 10, 60])
+        rec = {"tokens": toks, "limit": limit, "quick": quick}
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            try:
+                rec["segments"] = TextTokenizer.split_segments_by_token(toks, list(TextTokenizer.punctuation_marks_tokens), limit, quick)
+            except (AssertionError, RecursionError) as e:
+                rec["error"] = type(e).__name__
+            rec["warned"] = any(issubclass(w.category, RuntimeWarning) for w in caught)
+        out["split"].append(rec)
+    with open(os.path.join(HERE, "front.json"), "w", encoding="utf-8") as f:
+        json.dump(out, f, ensure_ascii=False, separators=(",", ":"))
+    print("front.json:", {k: (len(v) if isinstance(v, list) else "-") for k, v in out.items()},
+          "split errors", sum("error" in r for r in out["split"]), "warned", sum(r["warned"] for r in out["split"]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["aa", "bigvgan", "gpt", "prod", "sampler", "beam", "s2mel", "cond"]
+    which = sys.argv[1:] or ["aa", "bigvgan", "gpt", "prod", "sampler", "beam", "s2mel", "cond", "front"]
     if "aa" in which:
         gen_aa_snake()
     if "bigvgan" in which:
@@ -465,3 +554,5 @@ if __name__ == "__main__":
         gen_s2mel()
     if "cond" in which:
         gen_conditioning()
+    if "front" in which:
+        gen_front()

@@ -170,3 +170,41 @@ def test_infer_with_built_in_conditioning_and_s2mel():
     want = cpu.get_conditioning(spk.transpose(1, 2), ls)[0] + cpu.merge_emovec(spk, emo, ls, le, alpha=0.7)
     got = m.cond.get_conditioning(spk.to(dev).transpose(1, 2), ls.to(dev))[0] + m.cond.merge_emovec(spk.to(dev), emo.to(dev), ls.to(dev), le.to(dev), alpha=0.7)
     assert (got.cpu() - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())
+
+
+def test_infer_tokenises_raw_text_with_the_built_in_front_end():
+    """Row N4 inside `infer`: with a `TextTokenizer` the text goes through normalise -> CJK spacing -> sentencepiece ->
+    `split_segments` in this package (front.py / infer_v2.py:582-617); same audio as a glue handing over the same ids."""
+    import voice_tts_amd.weights as WR
+    from indextts.infer_v2 import IndexTTS2
+    from voice_tts_amd.front import TextNormalizer, TextTokenizer
+
+    class Identity:
+        def normalize(self, text):
+            return text
+
+    tok = TextTokenizer(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_bpe.model"),
+                        TextNormalizer(zh_normalizer=Identity(), en_normalizer=Identity()))
+    text = "今天是个好日子 it's a good day。最zhong4要的是：不要chong2蹈覆辙！where's the money?"
+    toks = tok.tokenize(text)
+    want_segments = [tok.convert_tokens_to_ids(s) for s in tok.split_segments(toks, 20)]
+    assert len(want_segments) >= 3
+
+    class IdsGlue(FakeGlue):
+        def tokenize(self, text, max_text_tokens_per_segment, quick_streaming_tokens=0):
+            return want_segments
+
+    class NoTokGlue(FakeGlue):
+        def tokenize(self, *a, **k):
+            raise AssertionError("the built-in tokenizer must be used")
+
+    dev = torch.device("cuda:0")
+    gcfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2, number_text_tokens=tok.vocab_size + 1)
+    bcfg = WR.tiny_bigvgan_cfg(64)
+    Wg, Wb = WR.make_gpt_weights(gcfg, seed=7), WR.make_bigvgan_weights(bcfg, seed=8)
+    kw = dict(cfg_path=None, model_dir="/nonexistent", device="cuda:0", gpt_state_dict=Wg, bigvgan_state_dict=Wb, gpt_cfg=gcfg, bigvgan_cfg=bcfg,
+              max_seq=192, max_frames=128)
+    gen = dict(max_text_tokens_per_segment=20, num_beams=1, top_k=1, max_mel_tokens=12)
+    sr_a, pcm_a = IndexTTS2(glue=NoTokGlue(128, dev), tokenizer=tok, **kw).infer("spk.wav", text, None, **gen)
+    sr_b, pcm_b = IndexTTS2(glue=IdsGlue(128, dev), **kw).infer("spk.wav", text, None, **gen)
+    assert sr_a == sr_b == 22050 and pcm_a.shape == pcm_b.shape and np.array_equal(pcm_a, pcm_b)

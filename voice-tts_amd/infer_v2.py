@@ -64,7 +64,8 @@ class Glue:
 class IndexTTS2:
     def __init__(self, cfg_path="models/IndexTTS/config.yaml", model_dir="models/IndexTTS", use_fp16=False, device=None,
                  use_cuda_kernel=None, use_deepspeed=False, *, glue=None, gpt_state_dict=None, bigvgan_state_dict=None,
-                 s2mel_state_dict=None, gpt_cfg=None, bigvgan_cfg=None, cond_cfg=None, s2mel_cfg=None, max_seq=2048, max_frames=4096):
+                 s2mel_state_dict=None, gpt_cfg=None, bigvgan_cfg=None, cond_cfg=None, s2mel_cfg=None, tokenizer=None,
+                 max_seq=2048, max_frames=4096):
         if device is None:
             if not torch.cuda.is_available():
                 raise RuntimeError("the HIP hot path needs a GPU (no CPU fallback); pass device='cuda:N'")
@@ -119,6 +120,16 @@ class IndexTTS2:
             from .s2mel import S2MEL_CFG, S2Mel
 
             self.s2mel = S2Mel(s2mel_state_dict, S2MEL_CFG if s2mel_cfg is None else s2mel_cfg, device=self.device)
+        # text front-end (row N4; infer_v2.py:161-165): a given tokenizer, else model_dir/<dataset.bpe_model> with the
+        # reference's normaliser (needs WeText, as there), else `glue.tokenize`
+        self.tokenizer = tokenizer
+        bpe = os.path.join(model_dir, (cfg.get("dataset") or {}).get("bpe_model", "")) if cfg.get("dataset") else None
+        if self.tokenizer is None and bpe and os.path.isfile(bpe):
+            from .front import TextNormalizer, TextTokenizer
+
+            self.normalizer = TextNormalizer()
+            self.tokenizer = TextTokenizer(bpe, self.normalizer)
+            logger.info(f"bpe model loaded from: {bpe}")
         # prompt caches (infer_v2.py:190-197)
         self.cache_spk_audio_prompt = None
         self.cache_spk = None
@@ -208,7 +219,17 @@ class IndexTTS2:
             self.cache_emo_audio_prompt = emo_audio_prompt
         emo_cond_emb = self.cache_emo_cond
 
-        segments = glue.tokenize(text, max_text_tokens_per_segment, quick_streaming_tokens)
+        if self.tokenizer is not None:  # infer_v2.py:582-589,617
+            text_tokens_list = self.tokenizer.tokenize(text)
+            text_token_ids = self.tokenizer.convert_tokens_to_ids(text_tokens_list)
+            unk = self.tokenizer.unk_token_id
+            if unk in text_token_ids:
+                logger.warning(f"Input text contains {text_token_ids.count(unk)} unknown tokens (id={unk})")
+                logger.warning(f"Tokens which can't be encoded: {[t for t, i in zip(text_tokens_list, text_token_ids) if i == unk]}")
+            segments = [self.tokenizer.convert_tokens_to_ids(sent) for sent in
+                        self.tokenizer.split_segments(text_tokens_list, max_text_tokens_per_segment, quick_streaming_tokens=quick_streaming_tokens)]
+        else:
+            segments = glue.tokenize(text, max_text_tokens_per_segment, quick_streaming_tokens)
         # generation kwargs and their defaults (infer_v2.py:598-606); do_sample is popped and then forced True (:648)
         generation_kwargs.pop("do_sample", True)
         top_p = generation_kwargs.pop("top_p", 0.8)
