@@ -76,7 +76,12 @@ int ixtts_attn_full_f32(const float* q_dev, const float* k_dev, const float* v_d
  *     output u [rows,2F]: out[r,j] = silu(u[r,j]) * u[r,F+j].
  * ixtts_wn_gate_f32        replaces fused_add_tanh_sigmoid_multiply (wavenet.py:142-160): out[b,c,t] =
  *     tanh(a[b,c,t] + g[b,off+c]) * sigmoid(a[b,C+c,t] + g[b,off+C+c]); a [B,2C,T], g [B,g_stride], out [B,C,T].
- * All tensors contiguous fp32 device memory; H, F multiples of 4, H <= 2048.
+ * ixtts_wn_gate_rows_f32   the same gate in row layout: a [rows,2C] -> out [rows,C], row r taking the gate biases of batch
+ *     entry min(r / rows_per_batch, B-1) (the WaveNet head keeps its sequences as rows so that every conv is a plain
+ *     row-major GEMM; rows between two sequences are computed and never read).
+ * ixtts_reflect_halo_rows_f32  refreshes the reflect padding (SConv1d pad_mode "reflect", wavenet.py:103-140) of a row-layout
+ *     buffer p [B, left+T+right, C] in place from its interior rows.
+ * All tensors contiguous fp32 device memory; H, F, C multiples of 4, H <= 2048.
  */
 int ixtts_adaln_rmsnorm_f32(const float* x_dev, const float* wb_dev, const float* g_dev, float* out_dev, int B, int T, int H, float eps,
                             void* stream);
@@ -84,6 +89,9 @@ int ixtts_ln_modulate_f32(const float* x_dev, const float* shift_scale_dev, floa
 int ixtts_rope_qk_f32(float* qkv_dev, const float* cos_sin_dev, int B, int T, int H, int head_dim, void* stream);
 int ixtts_swiglu_f32(const float* u_dev, float* out_dev, long rows, int F, void* stream);
 int ixtts_wn_gate_f32(const float* a_dev, const float* g_dev, float* out_dev, int B, int C, int T, long g_stride, int g_offset, void* stream);
+int ixtts_wn_gate_rows_f32(const float* a_dev, const float* g_dev, float* out_dev, long rows, int C, long rows_per_batch, int B, long g_stride,
+                           int g_offset, void* stream);
+int ixtts_reflect_halo_rows_f32(float* p_dev, int B, int T, int C, int left, int right, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Seam 2 -- BigVGAN-v2 generator

@@ -85,3 +85,33 @@ def test_rope_attention_path_matches_torch(dev):
     want = cpu._attention(qkv.clone(), B, T, None)
     got = gpu._attention(qkv.clone().to(dev), B, T, None).cpu()
     assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_wavenet_row_layout_matches_the_conv_form(dev):
+    """The WaveNet head with sequences as rows (`_wavenet_rows`: HIP gate + halo kernels around row-major library GEMMs) on
+    the GPU == the reference-form convs on the CPU; and the two row kernels alone == their torch branches."""
+    from voice_tts_amd import s2mel as S
+
+    g = torch.Generator().manual_seed(31)
+    rows, C_, B, rpb = 2 * 41 - 4, 64, 2, 41
+    a = torch.randn(rows, 2 * C_, generator=g) * 2
+    gv = torch.randn(B, 3 * 2 * C_, generator=g)
+    want = S.wn_gate_rows(a, gv, 2 * C_, C_, rpb)
+    got = S.wn_gate_rows(a.to(dev), gv.to(dev), 2 * C_, C_, rpb).cpu()
+    assert (got - want).abs().max().item() <= 2e-6
+    for left, right in ((2, 2), (3, 1), (0, 4)):
+        p = torch.randn(B, left + 37 + right, C_, generator=g)
+        want = S.reflect_halo_rows(p.clone(), 37, left, right)
+        got = S.reflect_halo_rows(p.clone().to(dev), 37, left, right).cpu()
+        assert torch.equal(got, want)
+        ref = torch.nn.functional.pad(p[:, left:left + 37].transpose(1, 2), (left, right), mode="reflect").transpose(1, 2)
+        assert torch.equal(want, ref)
+
+    cfg = S.tiny_s2mel_cfg()
+    W = S.make_s2mel_weights(cfg, seed=13)
+    cpu, gpu = S.S2Mel(W, cfg, "cpu"), S.S2Mel(W, cfg, dev)
+    x = torch.randn(2, cfg["wavenet_hidden"], 203, generator=g)
+    t2 = torch.randn(2, cfg["wavenet_hidden"], generator=g)
+    want = cpu._wavenet(x.clone(), torch.ones(2, 1, 203), t2, True)
+    got = gpu._wavenet_rows(x.transpose(1, 2).contiguous().to(dev), t2.to(dev)).transpose(1, 2).cpu() + cpu.wn_out_bias[None, :, None]
+    assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())

@@ -77,6 +77,10 @@ def test_wavenet_gemm_form_equals_the_conv_form():
     want = m._wavenet(x.clone(), torch.ones(2, 1, 37), t2, True)
     got = m._wavenet_gemm(x.clone(), t2) + m.wn_out_bias[None, :, None]
     assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    # sequences as rows, one GEMM per tap over all sequences (what the GPU runs for dilation 1)
+    rows = m._wavenet_rows(x.transpose(1, 2).contiguous(), t2).transpose(1, 2) + m.wn_out_bias[None, :, None]
+    assert rows.shape == want.shape
+    assert (rows - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
 
 
 def test_dit_head_on_the_needed_frames_only():

@@ -53,6 +53,8 @@ SYMBOLS = {
     "ixtts_rope_qk_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ixtts_swiglu_f32": (C.c_int, [_P, _P, C.c_long, C.c_int, _P]),
     "ixtts_wn_gate_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, _P]),
+    "ixtts_wn_gate_rows_f32": (C.c_int, [_P, _P, _P, C.c_long, C.c_int, C.c_long, C.c_int, C.c_long, C.c_int, _P]),
+    "ixtts_reflect_halo_rows_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ixtts_bigvgan_create": (C.c_int, [C.POINTER(_P), C.POINTER(BigVGANCfg)]),
     "ixtts_bigvgan_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int]),
     "ixtts_bigvgan_finalize": (C.c_int, [_P]),

@@ -109,6 +109,43 @@ __global__ __launch_bounds__(256) void wn_gate_kernel(const float* __restrict__ 
   out[idx] = tanhf(xa) * (1.0f / (1.0f + expf(-xb)));
 }
 
+// Row layout of the same gate: a [rows][2C], out [rows][C]; row r belongs to batch entry min(r / rows_per_batch, B-1)
+__global__ __launch_bounds__(256) void wn_gate_rows_kernel(const float* __restrict__ a, const float* __restrict__ gvec, float* __restrict__ out, long rows, int C,
+                                                           long rows_per_batch, int B, long gstride, int goff) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // one float4 of one output row
+  const int C4 = C >> 2;
+  if (idx >= rows * C4) return;
+  const long r = idx / C4;
+  const int c = (int)(idx % C4) * 4;
+  const int b = (int)min(r / rows_per_batch, (long)B - 1);
+  const float4 xa = *reinterpret_cast<const float4*>(a + r * 2 * C + c);
+  const float4 xb = *reinterpret_cast<const float4*>(a + r * 2 * C + C + c);
+  const float4 ga = *reinterpret_cast<const float4*>(gvec + b * gstride + goff + c);
+  const float4 gb = *reinterpret_cast<const float4*>(gvec + b * gstride + goff + C + c);
+  float4 o;
+  o.x = tanhf(xa.x + ga.x) * (1.0f / (1.0f + expf(-(xb.x + gb.x))));
+  o.y = tanhf(xa.y + ga.y) * (1.0f / (1.0f + expf(-(xb.y + gb.y))));
+  o.z = tanhf(xa.z + ga.z) * (1.0f / (1.0f + expf(-(xb.z + gb.z))));
+  o.w = tanhf(xa.w + ga.w) * (1.0f / (1.0f + expf(-(xb.w + gb.w))));
+  *reinterpret_cast<float4*>(out + r * C + c) = o;
+}
+
+// Reflect halo of a row-layout sequence buffer p [B][left + T + right][C]: halo row left-1-i = interior row i+1,
+// halo row left+T+i = interior row T-2-i (torch's reflect padding, wavenet.py's SConv1d pad_mode)
+__global__ __launch_bounds__(256) void reflect_halo_rows_kernel(float* __restrict__ p, int B, int T, int C, int left, int right) {
+  const int C4 = C >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per_b = (long)(left + right) * C4;
+  if (idx >= per_b * B) return;
+  const int b = (int)(idx / per_b);
+  const int h = (int)((idx % per_b) / C4);
+  const int c = (int)(idx % C4) * 4;
+  float* base = p + (long)b * (left + T + right) * C;
+  const int dst = h < left ? left - 1 - h : left + T + (h - left);
+  const int src = h < left ? left + h + 1 : left + T - 2 - (h - left);
+  *reinterpret_cast<float4*>(base + (long)dst * C + c) = *reinterpret_cast<const float4*>(base + (long)src * C + c);
+}
+
 }  // namespace ixtts
 
 using namespace ixtts;
@@ -159,6 +196,29 @@ extern "C" int ixtts_wn_gate_f32(const float* a_dev, const float* g_dev, float* 
   IX_ARG(B > 0 && C > 0 && T > 0 && g_offset >= 0, "wn_gate: bad shape B=%d C=%d T=%d", B, C, T);
   const long n = (long)B * C * T;
   hipLaunchKernelGGL(wn_gate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a_dev, g_dev, out_dev, B, C, T, g_stride, g_offset);
+  IX_HIP(hipGetLastError());
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_wn_gate_rows_f32(const float* a_dev, const float* g_dev, float* out_dev, long rows, int C, long rows_per_batch, int B, long g_stride,
+                                      int g_offset, void* stream) {
+  IX_ARG(a_dev && g_dev && out_dev, "wn_gate_rows: null pointer");
+  IX_ARG(rows > 0 && C > 0 && C % 4 == 0 && rows_per_batch > 0 && B > 0 && g_offset >= 0 && g_offset % 4 == 0 && g_stride % 4 == 0,
+         "wn_gate_rows: bad shape rows=%ld C=%d rows_per_batch=%ld B=%d", rows, C, rows_per_batch, B);
+  const long n = rows * (C / 4);
+  hipLaunchKernelGGL(wn_gate_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a_dev, g_dev, out_dev, rows, C, rows_per_batch, B,
+                     g_stride, g_offset);
+  IX_HIP(hipGetLastError());
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_reflect_halo_rows_f32(float* p_dev, int B, int T, int C, int left, int right, void* stream) {
+  IX_ARG(p_dev, "reflect_halo_rows: null pointer");
+  IX_ARG(B > 0 && C > 0 && C % 4 == 0 && left >= 0 && right >= 0 && T > left && T > right, "reflect_halo_rows: bad shape B=%d T=%d C=%d left=%d right=%d", B, T, C,
+         left, right);
+  const long n = (long)B * (left + right) * (C / 4);
+  if (n == 0) return IXTTS_OK;
+  hipLaunchKernelGGL(reflect_halo_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p_dev, B, T, C, left, right);
   IX_HIP(hipGetLastError());
   return IXTTS_OK;
 }

@@ -208,6 +208,35 @@ def wn_gate(a, g, off, C_):
     return torch.tanh(x[:, :C_]) * torch.sigmoid(x[:, C_:])
 
 
+def wn_gate_rows(a, g, off, C_, rows_per_batch):
+    """`wn_gate` in row layout: a [rows, 2C] -> [rows, C]; row r uses the gate biases of batch entry min(r // rows_per_batch, B-1)."""
+    rows, B = a.shape[0], g.shape[0]
+    if a.is_cuda:
+        a, g = a.contiguous(), g.contiguous()
+        out = torch.empty(rows, C_, device=a.device, dtype=a.dtype)
+        with torch.cuda.device(a.device):
+            _hip_call("ixtts_wn_gate_rows_f32", a.data_ptr(), g.data_ptr(), out.data_ptr(), rows, C_, rows_per_batch, B, g.shape[1], off)
+        return out
+    b = (torch.arange(rows, device=a.device) // rows_per_batch).clamp(max=B - 1)
+    x = a + g[b, off:off + 2 * C_]
+    return torch.tanh(x[:, :C_]) * torch.sigmoid(x[:, C_:])
+
+
+def reflect_halo_rows(p, T, left, right):
+    """Refresh, in place, the reflect padding of p [B, left+T+right, C] from its interior rows."""
+    B, _, C_ = p.shape
+    if p.is_cuda:
+        assert p.is_contiguous()
+        with torch.cuda.device(p.device):
+            _hip_call("ixtts_reflect_halo_rows_f32", p.data_ptr(), B, T, C_, left, right)
+        return p
+    if left:
+        p[:, :left] = p[:, left + 1:2 * left + 1].flip(1)
+    if right:
+        p[:, left + T:] = p[:, left + T - 1 - right:left + T - 1].flip(1)
+    return p
+
+
 TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunable", "gfx950_s2mel.csv")
 
 
@@ -433,6 +462,43 @@ class S2Mel:
             out = torch.bmm(r2, acts) if out is None else out.baddbmm_(r2, acts)
         return out
 
+    def _wavenet_rows(self, h, g):
+        """The same network with sequences as ROWS (h [B,T,C], dilation 1): every conv is a row-major GEMM `X W^T` (the
+        library's fast layout; the channel-major form above runs them at 0.6x the rate).  The B sequences sit in one
+        reflect-padded buffer [B, T+k-1, C]; tap j of the k-tap conv is that buffer, flattened, shifted by j rows, so ONE
+        GEMM per tap covers all sequences -- the k-1 rows that straddle two sequences are computed and never read (their
+        residual update lands in padding rows, which are refreshed before the next layer reads them).
+        Returns the skip sum [B,T,C] (a strided view) WITHOUT `wn_out_bias`."""
+        W, cfg = self.W, self.cfg
+        Hw, nl, k = cfg["wavenet_hidden"], cfg["wavenet_layers"], cfg["wavenet_kernel"]
+        assert cfg["wavenet_dilation_rate"] == 1
+        B, T_, _ = h.shape
+        p = "cfm.estimator.wavenet."
+        g = F.linear(g, W[p + "cond_layer.conv.conv.weight"][:, :, 0], W[p + "cond_layer.conv.conv.bias"])
+        tot = k - 1
+        right = tot // 2
+        left = tot - right
+        Tp = T_ + tot
+        P = torch.empty(B, Tp, Hw, device=h.device, dtype=h.dtype)
+        P[:, left:left + T_] = h
+        P2 = P.view(B * Tp, Hw)
+        M = B * Tp - tot
+        centre = P2[left:left + M]  # the input row under output row r
+        out = torch.empty(B * Tp, Hw, device=h.device, dtype=h.dtype)
+        for i in range(nl):
+            reflect_halo_rows(P, T_, left, right)
+            acc = torch.addmm(self.wn_bin[i], P2[:M], self.wn_taps[i][0].t())
+            for j in range(1, k):
+                acc.addmm_(P2[j:j + M], self.wn_taps[i][j].t())
+            acts = wn_gate_rows(acc, g, i * 2 * Hw, Hw, Tp)
+            if i < nl - 1:
+                centre.addmm_(acts, self.wn_r1[i].t())
+            if i == 0:
+                torch.mm(acts, self.wn_r2[i].t(), out=out[:M])
+            else:
+                out[:M].addmm_(acts, self.wn_r2[i].t())
+        return out.view(B, Tp, Hw)[:, :T_]
+
     # ------------------------------------------------------------------ DiT + CFM
     def dit_prepare(self, prompt_x, x_lens, style, cond):
         """Everything of DiT.forward that does not depend on (x, t): computed once per CFM solve instead of once per
@@ -474,13 +540,17 @@ class S2Mel:
             x_res, xt = x_res[:, lo:], xt[:, lo:]
         Th = T - lo
         x_res = F.linear(x_res, self.skipl_res, W[e + "skip_linear.bias"]) + F.linear(xt, self.skipl_x)
-        h = _lin(x_res, W, e + "conv1").transpose(1, 2)
+        h = _lin(x_res, W, e + "conv1")
         t2 = self._t_embed(t, e + "t_embedder2")
-        if h.is_cuda and ctx["full"] and Th > 2 * cfg["wavenet_kernel"] * cfg["wavenet_dilation_rate"] ** (cfg["wavenet_layers"] - 1):
-            h = self._wavenet_gemm(h, t2).transpose(1, 2) + F.linear(x_res, W[e + "res_projection.weight"], W[e + "res_projection.bias"] + self.wn_out_bias)
+        gemm_form = h.is_cuda and ctx["full"] and Th > 2 * cfg["wavenet_kernel"] * cfg["wavenet_dilation_rate"] ** (cfg["wavenet_layers"] - 1)
+        if gemm_form and cfg["wavenet_dilation_rate"] == 1:
+            h = self._wavenet_rows(h, t2) + F.linear(x_res, W[e + "res_projection.weight"], W[e + "res_projection.bias"] + self.wn_out_bias)
+        elif gemm_form:
+            h = self._wavenet_gemm(h.transpose(1, 2), t2).transpose(1, 2) + F.linear(x_res, W[e + "res_projection.weight"],
+                                                                                     W[e + "res_projection.bias"] + self.wn_out_bias)
         else:
             mask = ctx["x_mask"][:, :, lo:] if lo > 0 else ctx["x_mask"]
-            h = self._wavenet(h, mask, t2, ctx["full"]).transpose(1, 2) + _lin(x_res, W, e + "res_projection")
+            h = self._wavenet(h.transpose(1, 2), mask, t2, ctx["full"]).transpose(1, 2) + _lin(x_res, W, e + "res_projection")
         ss = _lin(F.silu(t1), W, e + "final_layer.adaLN_modulation.1")
         h = ln_modulate(h, ss)
         h = _lin(h, W, e + "final_layer.linear").transpose(1, 2)
