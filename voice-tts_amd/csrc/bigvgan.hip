@@ -40,7 +40,7 @@ struct ixtts_bigvgan {
   std::map<std::string, ActDesc> acts;
   float* arena = nullptr;
   size_t arena_floats = 0;
-  size_t filt_off = 0;
+  size_t filt_off = 0, zero_off = 0;
   float* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t buf_floats = 0;
   int total_up = 1;
@@ -132,6 +132,8 @@ extern "C" int ixtts_bigvgan_create(ixtts_bigvgan** out, const ixtts_bigvgan_cfg
     off += 4;
     h->convs["conv_post"] = d;
   }
+  h->zero_off = off;  // 64 floats that stay zero: where the conv kernel points loads it must not make (ConvParams::zeros)
+  off += 64;
   h->total_up = up;
   h->arena_floats = off;
   if (hipMalloc(&h->arena, off * sizeof(float)) != hipSuccess) {
@@ -292,6 +294,7 @@ static int run_conv(ixtts_bigvgan* h, const std::string& name, const float* x, f
   p.x = x;
   p.wp = h->arena + d.w_off;
   p.bias = d.has_bias ? h->arena + d.b_off : nullptr;
+  p.zeros = h->arena + h->zero_off;
   p.res = res;
   p.accum = accum;
   p.y = y;

@@ -11,6 +11,7 @@ struct ConvParams {
   const float* res;    // [B][Cout][Tout] or null  (residual)
   const float* accum;  // [B][Cout][Tout] or null  (running sum of the stage's resblocks)
   float* y;            // [B][Cout][Tout]
+  const float* zeros;  // >= 16 floats of zeros in device memory: the target of loads that must not happen (absent operand, padding)
   int B, Cin, Cin_pad, Cout, Cout_pad, Tin, Tout;
   int ntap, dil, off0;  // input index = q + off0 + tap*dil   (dil = -1 for a transposed-conv phase)
   int os, oo;           // output index = q*os + oo (+ phase when nphase > 1)

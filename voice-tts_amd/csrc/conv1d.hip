@@ -34,7 +34,7 @@ constexpr int CKG = 4;  // groups per K-chunk: the x tile in LDS covers 32 input
 // They stream from L2 (the XCD-aware tile map keeps one co-slice per XCD) straight into registers, one tap ahead;
 // only the x tile (+dilation halo) lives in LDS.
 template <int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
   constexpr int BM = 32 * MT * WM;
   constexpr int BN = 32 * NT * WN;
   static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -81,78 +81,103 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvParams p) {
   const size_t tstride = (size_t)ngroups * gstride;    // float4 per tap
   const int lo = q0 + p.off0 - (p.dil < 0 ? span : 0);  // smallest input index any tap of this tile touches
 
-  for (int g0 = 0; g0 < ngroups; g0 += CKG) {
-    const int ng = min(CKG, ngroups - g0);
-    __syncthreads();
-    // ---- stage x tile: ng*8 rows x XW columns (zero outside [0,Tin) / beyond Cin).  One channel group at a
-    // time: its 8 rows x up-to-2 columns per thread are all in flight before the first LDS store (16 temporaries;
-    // unrolling the whole 32-row chunk -- or a register-prefetched double buffer -- pushed the kernel past 200 VGPRs
-    // and to occupancy 1, which measured slower).
-    for (int gg = 0; gg < ng; ++gg) {
-      float v[CG][2];
+  // ---- x tiles: LDS-DMA (global_load_lds_dword: no VGPRs, no ds_write pass) into two buffers, the copy of chunk g+1 in
+  // flight under the MFMAs of chunk g.  A chunk is 32 channel rows x XW columns; a wave copies 8 rows in pieces of 64
+  // columns (the last piece of a row is shifted back to end at column XW: it rewrites a few columns with the same
+  // values instead of spilling into the next row).  Every lane supplies its own source address, so padding (t outside
+  // [0,Tin), channels beyond Cin) reads the zero page -- no branches, and all 32 rows are always staged, which lets the
+  // ragged last chunk run the same MFMA sequence with zeroed weights.
+  const int nchunks = (ngroups + CKG - 1) / CKG;
+  const int np = (XW + 63) >> 6;
+  auto issue_dma = [&](int g, int buf) {
+    const int c0 = min(g, nchunks - 1) * (CKG * CG) + wave * 8;
+    float* dst0 = Xs + (size_t)buf * (CKG * CG) * XWP + (wave * 8) * XWP;
+    for (int pc = 0; pc < np; ++pc) {
+      const int cs = (pc < np - 1) ? pc * 64 : XW - 64;
+      const int t = lo + cs + lane;
+      const bool tvalid = t >= 0 && t < p.Tin;
 #pragma unroll
-      for (int r = 0; r < CG; ++r) {
-        const int c = (g0 + gg) * CG + r;
-        const float* xr = xb + (size_t)c * p.Tin;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int j = tid + jj * 256, t = lo + j;
-          v[r][jj] = (j < XW && c < p.Cin && t >= 0 && t < p.Tin) ? xr[t] : 0.f;
-        }
+      for (int r = 0; r < 8; ++r) {
+        const int c = c0 + r;
+        const float* src = (tvalid && c < p.Cin) ? xb + (size_t)c * p.Tin + t : p.zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst0 + r * XWP + cs), 4, 0, 0);
       }
-#pragma unroll
-      for (int r = 0; r < CG; ++r)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int j = tid + jj * 256;
-          if (j < XW) Xs[(gg * CG + r) * XWP + j] = v[r][jj];
-        }
     }
-    __syncthreads();
-    const float* Xc = Xs;
-    // ---- taps: A fragments one tap ahead in registers, B fragments from the LDS tile at a shifted offset
-    float4 a_cur[CKG][MT], a_nxt[CKG][MT];
+  };
+  // A fragments of (chunk g, tap): unconditional loads, indices clamped; groups beyond the matrix are zeroed when used
+  auto load_a = [&](float4 (&a)[CKG][MT], int g, int tap) {
 #pragma unroll
     for (int gg = 0; gg < CKG; ++gg)
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a_cur[gg][i] = (gg < ng) ? wq[(size_t)(g0 + gg) * gstride + i * 32] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int tap = 0; tap < p.ntap; ++tap) {
-      if (tap + 1 < p.ntap) {
+      for (int i = 0; i < MT; ++i) a[gg][i] = wq[(size_t)tap * tstride + (size_t)min(g * CKG + gg, ngroups - 1) * gstride + i * 32];
+  };
+  auto load_b = [&](float (&bq)[4][NT], const float* xrow, int gg) {
 #pragma unroll
-        for (int gg = 0; gg < CKG; ++gg)
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
-            a_nxt[gg][i] = (gg < ng) ? wq[(size_t)(tap + 1) * tstride + (size_t)(g0 + gg) * gstride + i * 32] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      const int xoff = (p.dil >= 0) ? tap * adil : (p.ntap - 1 - tap) * adil;
-      const float* xrow = Xc + lh * XWP + wn * (32 * NT) + l31 + xoff;
+      for (int j = 0; j < NT; ++j) bq[kk][j] = xrow[(gg * CG + 2 * kk) * XWP + j * 32];
+  };
+  float4 a_cur[CKG][MT], a_nxt[CKG][MT];
+  // one tap of one chunk: B fragments of the next group (and of the next tap's first group) are read while this group's
+  // 16 MFMAs run; A fragments of the next (chunk, tap) are loaded at entry
+  auto run_tap = [&](const float* Xc, int g, int tap) {
+    const bool last_tap = tap + 1 >= p.ntap;
+    load_a(a_nxt, last_tap ? min(g + 1, nchunks - 1) : g, last_tap ? 0 : tap + 1);
+    const int xoff = (p.dil >= 0) ? tap * adil : (p.ntap - 1 - tap) * adil;
+    const float* xrow = Xc + lh * XWP + wn * (32 * NT) + l31 + xoff;
+    float bq[2][4][NT];
+    load_b(bq[0], xrow, 0);
 #pragma unroll
-      for (int gg = 0; gg < CKG; ++gg) {
-        if (gg < ng) {
+    for (int gg = 0; gg < CKG; ++gg) {
+      if (gg + 1 < CKG) load_b(bq[(gg + 1) & 1], xrow, gg + 1);
+      __builtin_amdgcn_sched_barrier(0);  // the next group's LDS reads go out before this group's MFMAs
+      const bool live = g * CKG + gg < ngroups;
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            float bb[NT];
+      for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bb[j] = xrow[(gg * CG + 2 * kk) * XWP + j * 32];
+        for (int i = 0; i < MT; ++i) {
+          float av = kk == 0 ? a_cur[gg][i].x : kk == 1 ? a_cur[gg][i].y : kk == 2 ? a_cur[gg][i].z : a_cur[gg][i].w;
+          av = live ? av : 0.f;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-              const float av = kk == 0 ? a_cur[gg][i].x : kk == 1 ? a_cur[gg][i].y : kk == 2 ? a_cur[gg][i].z : a_cur[gg][i].w;
-#pragma unroll
-              for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bb[j], acc[i][j], 0, 0, 0);
-            }
-          }
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[gg & 1][kk][j], acc[i][j], 0, 0, 0);
         }
       }
-#pragma unroll
-      for (int gg = 0; gg < CKG; ++gg)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) a_cur[gg][i] = a_nxt[gg][i];
     }
-  }
+#pragma unroll
+    for (int gg = 0; gg < CKG; ++gg)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a_cur[gg][i] = a_nxt[gg][i];
+  };
 
-  // ---- epilogue: bias, residual, 3-way accumulate, /3
+  issue_dma(0, 0);
+  load_a(a_cur, 0, 0);
+  for (int g = 0; g < nchunks; ++g) {
+    // own copies of chunk g have landed (they are older than the CKG*MT A loads still in flight), then everybody's
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CKG * MT) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const float* Xc = Xs + (size_t)(g & 1) * (CKG * CG) * XWP;
+    run_tap(Xc, g, 0);
+    // the other buffer was last read in chunk g-1, which every wave left before the barrier above.  Issued after the
+    // first tap so that waiting for that tap's A prefetch (older, in-order counter) does not wait for these copies
+    issue_dma(g + 1, (g + 1) & 1);
+    for (int tap = 1; tap < p.ntap; ++tap) run_tap(Xc, g, tap);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus copy of the last iteration, before the workgroup's LDS is released
+
+  // ---- epilogue: bias, residual, 3-way accumulate, /3.  Every operand load is unconditional and issued before the first
+  // store of its 32x32 block (absent operands and out-of-range elements read the zero page / a clamped element): loads
+  // under the bounds branch were waited for one by one, 64+ dependent round trips per lane.
   const size_t ob = (size_t)b * p.Cout * p.Tout;
   const int ophase = p.oo + (p.nphase > 1 ? phase : 0);
+  float bv[MT][16];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = min(m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.Cout - 1);
+      bv[i][r] = *(p.bias ? p.bias + m : p.zeros);
+    }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -160,18 +185,24 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvParams p) {
       const int q = q0 + wn * (32 * NT) + j * 32 + l31;
       const int t = q * p.os + ophase;
       const bool tv = (q < p.Nq) && (t >= 0) && (t < p.Tout);
+      const int tc = min(max(t, 0), p.Tout - 1);
+      float rv[16], av[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = min(m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.Cout - 1);
+        const size_t o = ob + (size_t)m * p.Tout + tc;
+        rv[r] = *(p.res ? p.res + o : p.zeros);
+        av[r] = *(p.accum ? p.accum + o : p.zeros);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (tv && m < p.Cout) {
-          const size_t o = ob + (size_t)m * p.Tout + t;
-          float v = acc[i][j][r];
-          if (p.bias) v += p.bias[m];
-          if (p.res) v += p.res[o];
-          if (p.accum) v = p.accum[o] + v;
-          if (p.div3) v = v / 3.0f;
-          p.y[o] = v;
-        }
+        float v = acc[i][j][r];
+        if (p.bias) v += bv[i][r];
+        if (p.res) v += rv[r];
+        if (p.accum) v = av[r] + v;
+        if (p.div3) v = v / 3.0f;
+        if (tv && m < p.Cout) p.y[ob + (size_t)m * p.Tout + t] = v;
       }
     }
   }
@@ -186,7 +217,7 @@ static int launch_cfg(const ConvParams& p0, hipStream_t st) {
   IX_ARG(p.Cout_pad % BM == 0 && p.Cout_pad >= p.m_tiles * BM, "conv: Cout_pad %d not a multiple of BM %d", p.Cout_pad, BM);
   int adil = p.dil < 0 ? -p.dil : p.dil;
   int XWP = (BN + (p.ntap - 1) * adil) | 1;
-  size_t smem = (size_t)(CKG * CG * XWP) * sizeof(float);
+  size_t smem = (size_t)(2 * CKG * CG * XWP) * sizeof(float);  // two x-tile buffers
   IX_ARG(smem <= 160 * 1024, "conv: LDS tile %zu B too large", smem);
   IX_ARG(BN + (p.ntap - 1) * adil <= 512, "conv: x tile of %d columns exceeds the staging bound (512)", BN + (p.ntap - 1) * adil);
   auto kern = conv1d_mfma_kernel<MT, NT, WM, WN>;
