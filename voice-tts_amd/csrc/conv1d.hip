@@ -121,16 +121,28 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
   float4 a_cur[CKG][MT], a_nxt[CKG][MT];
   // one tap of one chunk: B fragments of the next group (and of the next tap's first group) are read while this group's
   // 16 MFMAs run; A fragments of the next (chunk, tap) are loaded at entry
+  float bcarry[4][NT];  // B fragments of the next tap's first group, read under the current tap's last group
   auto run_tap = [&](const float* Xc, int g, int tap) {
     const bool last_tap = tap + 1 >= p.ntap;
     load_a(a_nxt, last_tap ? min(g + 1, nchunks - 1) : g, last_tap ? 0 : tap + 1);
     const int xoff = (p.dil >= 0) ? tap * adil : (p.ntap - 1 - tap) * adil;
+    const int tap_n = last_tap ? tap : tap + 1;  // (past the last tap of a chunk the carried fragments are not used)
+    const int xoff_n = (p.dil >= 0) ? tap_n * adil : (p.ntap - 1 - tap_n) * adil;
     const float* xrow = Xc + lh * XWP + wn * (32 * NT) + l31 + xoff;
+    const float* xrow_n = Xc + lh * XWP + wn * (32 * NT) + l31 + xoff_n;
     float bq[2][4][NT];
-    load_b(bq[0], xrow, 0);
+    if (tap == 0) {
+      load_b(bq[0], xrow, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bq[0][kk][j] = bcarry[kk][j];
+    }
 #pragma unroll
     for (int gg = 0; gg < CKG; ++gg) {
       if (gg + 1 < CKG) load_b(bq[(gg + 1) & 1], xrow, gg + 1);
+      else load_b(bcarry, xrow_n, 0);
       __builtin_amdgcn_sched_barrier(0);  // the next group's LDS reads go out before this group's MFMAs
       const bool live = g * CKG + gg < ngroups;
 #pragma unroll
