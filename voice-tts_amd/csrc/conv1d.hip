@@ -89,9 +89,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
   // ragged last chunk run the same MFMA sequence with zeroed weights.
   const int nchunks = (ngroups + CKG - 1) / CKG;
   const int np = (XW + 63) >> 6;
-  auto issue_dma = [&](int g, int buf) {
+  auto issue_dma = [&](int g, float* __restrict__ dst) {
     const int c0 = min(g, nchunks - 1) * (CKG * CG) + wave * 8;
-    float* dst0 = Xs + (size_t)buf * (CKG * CG) * XWP + (wave * 8) * XWP;
+    float* dst0 = dst + (wave * 8) * XWP;
     for (int pc = 0; pc < np; ++pc) {
       const int cs = (pc < np - 1) ? pc * 64 : XW - 64;
       const int t = lo + cs + lane;
@@ -162,19 +162,22 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
       for (int i = 0; i < MT; ++i) a_cur[gg][i] = a_nxt[gg][i];
   };
 
-  issue_dma(0, 0);
+  issue_dma(0, Xs);
   load_a(a_cur, 0, 0);
-  for (int g = 0; g < nchunks; ++g) {
+  // (`cur` / `nxt` restrict-qualified: the compiler then knows the tile being read is not the one the copies in flight
+  // write; without that it puts a vmcnt(0) -- a wait for the NEXT chunk -- in front of the LDS reads that follow the issue)
+  auto chunk_step = [&](int g, const float* __restrict__ cur, float* __restrict__ nxt) {
     // own copies of chunk g have landed (they are older than the CKG*MT A loads still in flight), then everybody's
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CKG * MT) : "memory");
     __builtin_amdgcn_s_barrier();
-    const float* Xc = Xs + (size_t)(g & 1) * (CKG * CG) * XWP;
-    run_tap(Xc, g, 0);
+    run_tap(cur, g, 0);
     // the other buffer was last read in chunk g-1, which every wave left before the barrier above.  Issued after the
     // first tap so that waiting for that tap's A prefetch (older, in-order counter) does not wait for these copies
-    issue_dma(g + 1, (g + 1) & 1);
-    for (int tap = 1; tap < p.ntap; ++tap) run_tap(Xc, g, tap);
-  }
+    issue_dma(g + 1, nxt);
+    for (int tap = 1; tap < p.ntap; ++tap) run_tap(cur, g, tap);
+  };
+  const int bufsz = (CKG * CG) * XWP;
+  for (int g = 0; g < nchunks; ++g) chunk_step(g, Xs + (g & 1) * bufsz, Xs + ((g + 1) & 1) * bufsz);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus copy of the last iteration, before the workgroup's LDS is released
 
   // ---- epilogue: bias, residual, 3-way accumulate, /3.  Every operand load is unconditional and issued before the first
