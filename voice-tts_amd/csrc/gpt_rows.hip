@@ -443,6 +443,187 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsArgs a) {
   if (threadIdx.x < 64) store_kv(reinterpret_cast<OT*>(a.out) + (size_t)row * a.D + hh * HD + threadIdx.x, o);
 }
 
+// ---- the same attention as a causal flash kernel on the fp32 matrix cores (the latent pass: 1237 rows x 20 heads; the
+// row-at-a-time kernel above re-streams every row's whole key prefix from L2: 94 GB per pass, 6.5 of its 10.4 ms).
+// Structure of csrc/attn_full.hip (S^T = K Q^T leaves, in accumulator register r of lane l, the score of query l&31 against
+// key (r&3)+8(r>>2)+4(l>>5), which is exactly the B operand of O^T += V^T P^T; one query column per lane, online softmax
+// in per-lane scalars, scores in the log2 domain) plus: K/V come from the cache in its own type and are widened to fp32
+// while staged; key k is visible to query row t iff valid_from <= k <= pos0 + t; a wave skips the tiles that lie
+// entirely behind its last query's limit (it still keeps the workgroup's barriers).  One workgroup = 4 waves = 128 rows.
+constexpr int FR_KT = 64, FR_KP = HD + 4;
+
+template <typename KVT>
+__device__ __forceinline__ void load_row16(const KVT* p, float (&v)[16]);
+template <>
+__device__ __forceinline__ void load_row16<float>(const float* p, float (&v)[16]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 t = reinterpret_cast<const float4*>(p)[i];
+    v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+  }
+}
+template <>
+__device__ __forceinline__ void load_row16<bf16>(const bf16* p, float (&v)[16]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const uint4 r = reinterpret_cast<const uint4*>(p)[i];
+    v[8 * i] = lo_bf16(r.x); v[8 * i + 1] = hi_bf16(r.x); v[8 * i + 2] = lo_bf16(r.y); v[8 * i + 3] = hi_bf16(r.y);
+    v[8 * i + 4] = lo_bf16(r.z); v[8 * i + 5] = hi_bf16(r.z); v[8 * i + 6] = lo_bf16(r.w); v[8 * i + 7] = hi_bf16(r.w);
+  }
+}
+
+template <typename KVT, typename OT>
+__global__ __launch_bounds__(256) void attn_rows_flash_kernel(AttnRowsArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ks[FR_KT * FR_KP];
+  __shared__ __attribute__((aligned(16))) float Vs[FR_KT * HD];
+  const int hh = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int qw0 = blockIdx.y * 128 + wave * 32;  // first row of this wave
+  const KVT* kb = reinterpret_cast<const KVT*>(a.kcache) + (size_t)hh * a.smax * HD;
+  const KVT* vb = reinterpret_cast<const KVT*>(a.vcache) + (size_t)hh * a.smax * HD;
+  const int last_key = a.pos0 + a.T - 1;  // last cache row this pass has written
+
+  float qr[HD / 2];  // Q[row l31][d = 8m + 4 lh + i] for k-step 4m + i, scaled by log2(e) / sqrt(64)
+  {
+    const int qi = min(qw0 + l31, a.T - 1);
+    const float* qp = a.q + (size_t)qi * a.D + hh * HD + 4 * lh;
+    const float qs = 0.125f * 1.4426950408889634f;
+#pragma unroll
+    for (int m = 0; m < HD / 8; ++m) {
+      const float4 t = *reinterpret_cast<const float4*>(qp + 8 * m);
+      qr[4 * m] = t.x * qs; qr[4 * m + 1] = t.y * qs; qr[4 * m + 2] = t.z * qs; qr[4 * m + 3] = t.w * qs;
+    }
+  }
+  f32x16 ot[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[j][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int lim = a.pos0 + qw0 + l31;             // last key this lane's row may see
+  const int wave_lim = a.pos0 + min(qw0 + 31, a.T - 1);  // ... and any row of this wave
+  const int wg_lim = a.pos0 + min((int)blockIdx.y * 128 + 127, a.T - 1);
+  const int t_first = (a.valid_from / FR_KT) * FR_KT;
+
+  for (int t0 = t_first; t0 <= wg_lim; t0 += FR_KT) {
+    __syncthreads();
+    {  // stage 64 keys x 64 dims of K and V, widened to fp32: each thread one quarter row of each
+      const int key = threadIdx.x >> 2, c16 = (threadIdx.x & 3) * 16;
+      const int t = min(t0 + key, last_key);  // rows past the pass repeat its last one (finite; masked below)
+      float kv[16], vv[16];
+      load_row16<KVT>(kb + (size_t)t * HD + c16, kv);
+      load_row16<KVT>(vb + (size_t)t * HD + c16, vv);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<float4*>(Ks + key * FR_KP + c16 + 4 * i) = make_float4(kv[4 * i], kv[4 * i + 1], kv[4 * i + 2], kv[4 * i + 3]);
+        *reinterpret_cast<float4*>(Vs + key * HD + c16 + 4 * i) = make_float4(vv[4 * i], vv[4 * i + 1], vv[4 * i + 2], vv[4 * i + 3]);
+      }
+    }
+    __syncthreads();
+    if (t0 > wave_lim) continue;  // wave-uniform: nothing in this tile is visible to this wave's rows
+
+    f32x16 st[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[j][r] = 0.f;
+    const float* kp0 = Ks + l31 * FR_KP + 4 * lh;
+    const float* kp1 = kp0 + 32 * FR_KP;
+    float4 ka[2][2];
+    ka[0][0] = *reinterpret_cast<const float4*>(kp0);
+    ka[0][1] = *reinterpret_cast<const float4*>(kp1);
+#pragma unroll
+    for (int m = 0; m < HD / 8; ++m) {
+      if (m + 1 < HD / 8) {
+        ka[(m + 1) & 1][0] = *reinterpret_cast<const float4*>(kp0 + 8 * (m + 1));
+        ka[(m + 1) & 1][1] = *reinterpret_cast<const float4*>(kp1 + 8 * (m + 1));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float4 kk4 = ka[m & 1][j];
+        st[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk4.x, qr[4 * m], st[j], 0, 0, 0);
+        st[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk4.y, qr[4 * m + 1], st[j], 0, 0, 0);
+        st[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk4.z, qr[4 * m + 2], st[j], 0, 0, 0);
+        st[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk4.w, qr[4 * m + 3], st[j], 0, 0, 0);
+      }
+    }
+    // causal / left-padding mask (only the first and the diagonal tiles have masked keys)
+    if (t0 < a.valid_from || t0 + FR_KT - 1 > a.pos0 + qw0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key < a.valid_from || key > lim) st[j][r] = -INFINITY;
+        }
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, st[j][r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    // (a tile may be all -inf for a lane -- behind its limit: alpha = 1, weights 0.  A left-padding row, t < valid_from,
+    // sees no key at all: its maximum stays -inf and is replaced by 0 in the exponents, so it ends as a row of zeros,
+    // finite like everything else that reaches the cache)
+    const float mn = fmaxf(m_run, tmax);
+    const float mref = (mn == -INFINITY) ? 0.f : mn;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - mref);
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pw = __builtin_amdgcn_exp2f(st[j][r] - mref);
+        st[j][r] = pw;
+        psum += pw;
+      }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = mn;
+    if (alpha != 1.0f) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[j][r] *= alpha;
+    }
+    const float* vp = Vs + (4 * lh) * HD + l31;
+    float va[2][2];
+    va[0][0] = vp[0];
+    va[0][1] = vp[32];
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) {
+      const int j = s2 >> 4, r = s2 & 15;
+      if (s2 + 1 < 32) {
+        const int j1 = (s2 + 1) >> 4, r1 = (s2 + 1) & 15;
+        const float* vrow = vp + (j1 * 32 + (r1 & 3) + 8 * (r1 >> 2)) * HD;
+        va[(s2 + 1) & 1][0] = vrow[0];
+        va[(s2 + 1) & 1][1] = vrow[32];
+      }
+      const float pv = st[j][r];
+      ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s2 & 1][0], pv, ot[0], 0, 0, 0);
+      ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s2 & 1][1], pv, ot[1], 0, 0, 0);
+    }
+  }
+  const int qi = qw0 + l31;
+  if (qi < a.T) {
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    OT* op = reinterpret_cast<OT*>(a.out) + (size_t)qi * a.D + hh * HD;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) store_kv(op + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, ot[j][r] * inv);
+  }
+}
+
+template <typename KVT, typename OT>
+static void launch_attn_rows(ixtts_gpt* h, const AttnRowsArgs& a, hipStream_t st) {
+  static const bool legacy = getenv("IXTTS_ROWS_ATTN") && !strcmp(getenv("IXTTS_ROWS_ATTN"), "legacy");  // A/B switch
+  if (legacy) hipLaunchKernelGGL((attn_rows_kernel<KVT, OT>), dim3(h->H, a.T), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((attn_rows_flash_kernel<KVT, OT>), dim3(h->H, ceil_div(a.T, 128)), dim3(256), 0, st, a);
+}
+
 template <typename WT, typename KVT, int EPI>
 static void launch_gemm(const GemmArgs& g, hipStream_t st) {
   // 128-row tiles once there are enough rows to fill the GPU with them (latent pass), 64-row tiles for prompts
@@ -468,7 +649,7 @@ static int forward_rows_t(ixtts_gpt* h, int slot, int T, int pos0, int valid_fro
     launch_gemm<WT, KVT, RE_QKV>(g, st);
     AttnRowsArgs a;
     a.q = h->rq; a.kcache = kc; a.vcache = vc; a.out = h->ratt; a.T = T; a.D = D; a.smax = h->smax; a.pos0 = pos0; a.valid_from = valid_from;
-    hipLaunchKernelGGL(attn_rows_kernel<KVT>, dim3(h->H, T), dim3(256), 0, st, a);
+    launch_attn_rows<KVT, float>(h, a, st);
     g.A = h->ratt; g.wt = A_PTR(o.wo); g.bias = A_F32(o.bo); g.out = h->rx; g.N = D; g.K = D;
     launch_gemm<WT, KVT, RE_RESID>(g, st);
     hipLaunchKernelGGL(ln_rows_kernel<D>, dim3(ceil_div(T, 4)), dim3(256), 0, st, h->rx, h->rxn, T);
@@ -510,7 +691,7 @@ static int forward_rows_bf16(ixtts_gpt* h, int slot, int T, int pos0, int valid_
     hipLaunchKernelGGL((gemm_rows_bf16_kernel<RE_QKV, KVT>), grid(g.N), blk, G16_SMEM, st, g);
     AttnRowsArgs a;
     a.q = h->rq; a.kcache = kc; a.vcache = vc; a.out = att16; a.T = T; a.D = D; a.smax = h->smax; a.pos0 = pos0; a.valid_from = valid_from;
-    hipLaunchKernelGGL((attn_rows_kernel<KVT, bf16>), dim3(h->H, T), blk, 0, st, a);
+    launch_attn_rows<KVT, bf16>(h, a, st);
     g.A = reinterpret_cast<const unsigned short*>(att16); g.wt = reinterpret_cast<const unsigned short*>(A_PTR(o.wo)); g.bias = A_F32(o.bo);
     g.out = h->rx; g.N = D; g.K = D;
     hipLaunchKernelGGL((gemm_rows_bf16_kernel<RE_RESID, KVT>), grid(g.N), blk, G16_SMEM, st, g);
