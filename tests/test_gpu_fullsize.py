@@ -72,6 +72,40 @@ def test_gpt_24_layers_bf16_token_agreement(gpt_full, dev):
     assert out.tolist()[0] == ids[0] or margins[0] < 0.05 * float(logits.abs().max())
 
 
+@pytest.mark.parametrize("B", [1, 2, 3])
+def test_fused_mlp_kernel_matches_the_split_kernels(gpt_full, dev, monkeypatch, B):
+    """bf16 decode at full size: the opt-in fused MLP launch (IXTTS_MLP=fused: LN2 + c_fc + gelu + c_proj with the hand-off
+    inside each XCD, partial sums completed by the next layer's QKV kernel) against the default split FC / MLP-out launches.
+    The two sum c_proj in different orders, so logits agree to rounding (not bit for bit) and greedy tokens are the same; the
+    hand-off must never time out (a time-out makes `read` raise)."""
+    import voice_tts_amd.weights as WR
+    from voice_tts_amd.gpt_engine import GptEngine
+
+    W, orc, conds, text, embeds, mask, ids, margins, logits = gpt_full
+    n = 40
+
+    def run(split):
+        if split:
+            monkeypatch.delenv("IXTTS_MLP", raising=False)
+        else:
+            monkeypatch.setenv("IXTTS_MLP", "fused")
+        eng = GptEngine(WR.GPT_CFG, dtype="bf16", max_seq=256, max_batch=B, device=dev).load_state_dict(W)
+        for b in range(B):
+            eng.prefill(b, embeds[: embeds.shape[0] - 3 * b], 0)  # different lengths per slot
+        eng.decode(B, 1, repetition_penalty=10.0, suppress_stop=True)
+        first = [eng.read_logits(b).copy() for b in range(B)]
+        eng.decode(B, n - 1, repetition_penalty=10.0, suppress_stop=True)
+        return first, [eng.read(b)[0][:n].tolist() for b in range(B)], [eng.read_logits(b).copy() for b in range(B)]
+
+    f1, t1, l1 = run(False)
+    f2, t2, l2 = run(True)
+    scale = max(float(np.abs(x).max()) for x in f2)
+    for b in range(B):
+        assert np.abs(f1[b] - f2[b]).max() <= 2e-3 * scale, (b, np.abs(f1[b] - f2[b]).max(), scale)
+        assert t1[b] == t2[b], (b, [i for i, (x, y) in enumerate(zip(t1[b], t2[b])) if x != y][:3])
+        assert np.abs(l1[b] - l2[b]).max() <= 5e-3 * scale
+
+
 def test_bigvgan_full_size_waveform(dev):
     """Production generator (1536 channels, 112 M params): waveform within 1e-3 max-abs of the CPU oracle
     (north_star); asserted at 2e-4."""

@@ -79,6 +79,13 @@ struct ixtts_gpt {
   // decode graphs per (batch, attention bucket): [.][NBKT] is the any-length legacy attention kernel
   hipGraphExec_t step_exec[ixtts::MAXB + 1][ixtts::NBKT + 1] = {};   // 1 decode step
   hipGraphExec_t multi_exec[ixtts::MAXB + 1][ixtts::NBKT + 1] = {};  // STEPS_PER_GRAPH steps
+  // fused MLP (mlp_fused_kernel): bf16 weights, model_dim 1280, workgroup i on XCD i % 8 (probed), IXTTS_MLP != "split"
+  bool mlp_fused = false;
+  void* wprx = nullptr;        // [L-1][8][1280][640] bf16: c_proj repacked per XCD
+  float* mlp_part = nullptr;   // [8][slots][1280]
+  unsigned* mlp_ctr = nullptr; // [L][8*32 + 32]: per-layer, per-XCD arrival counters (+ a timeout mark)
+  float* h2 = nullptr;         // second residual buffer (IN_LN_PART publishes the completed stream into the other one)
+  float* hc = nullptr;         // the residual buffer the launch being issued works on
   bool attn_split = true;  // IXTTS_ATTN=legacy turns the split-S kernel off (A/B timing, fallback test)
   int attn_bucket = ixtts::NBKT;  // bucket the graph being captured is built for
   int host_prompt_len[ixtts::MAXB + 2];

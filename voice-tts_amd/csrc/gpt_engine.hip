@@ -15,6 +15,8 @@
 //   wavefront streams whole rows with 16-byte-per-lane loads; vectors stay fp32.
 //   KV cache: [layer][slot][head][max_seq][64] (fp32 in parity mode, bf16 in throughput mode).
 #define IXTTS_ENGINE_TU 1
+#include <type_traits>
+
 #include "gpt_engine.h"
 #include "gpt_kernels.h"
 
@@ -33,7 +35,7 @@ static int launch_gemv(const GemvArgs& a, hipStream_t st) {
   const int n_units = (a.N + ROWS - 1) / ROWS;
   const int grid = ceil_div(n_units, WPB * UNITS);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), 0, st, a.wt, a.xin, a.bias, a.out, a.N, a.slot0, a.out_stride, a.smax, a.kcache, a.vcache,
-                     a.cur_len, a.heads, a.nsplit, a.ln_w, a.ln_b IXTTS_TRACE_ARG);
+                     a.cur_len, a.heads, a.nsplit, a.ln_w, a.ln_b, a.aux, a.xout IXTTS_TRACE_ARG);
   return IXTTS_OK;
 }
 
@@ -51,7 +53,7 @@ static int launch_gemv_lds(const GemvArgs& a, hipStream_t st) {
   const int n_units = (a.N + ROWS - 1) / ROWS;
   const int grid = ceil_div(n_units, WPB * UNITS);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), smem, st, a.wt, a.xin, a.bias, a.out, a.N, a.slot0, a.out_stride, a.smax, a.kcache,
-                     a.vcache, a.cur_len, a.heads, a.nsplit, a.ln_w, a.ln_b IXTTS_TRACE_ARG);
+                     a.vcache, a.cur_len, a.heads, a.nsplit, a.ln_w, a.ln_b, a.aux, a.xout IXTTS_TRACE_ARG);
   return IXTTS_OK;
 }
 
@@ -65,7 +67,7 @@ static int gemv_qkv(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.bias = A_F32(o.bqkv);
   a.N = 3 * D;
   a.slot0 = slot0;
-  a.xin = h->h;
+  a.xin = h->hc;
   a.out = h->q;
   a.out_stride = D;
   const size_t lstride = (size_t)h->slots * D * h->smax * sizeof(KVT);
@@ -74,6 +76,20 @@ static int gemv_qkv(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.cur_len = h->cur_len;
   a.smax = h->smax;
   a.heads = h->H;
+  if constexpr (std::is_same<WT, bf16>::value && D == MLP_D) {
+    if (h->mlp_fused) {
+      if (l + 1 < h->L) a.aux = h->mlp_ctr + (size_t)l * MLP_CTR_STRIDE;  // this layer's MLP is fused: clear its counters
+      if (l > 0) {  // the previous layer's MLP left 8 partial sums: complete the residual stream into the other buffer
+        a.ln_w = h->mlp_part;
+        a.ln_b = A_F32(h->lo[l - 1].bpr);
+        a.nsplit = h->slots;
+        a.xout = (h->hc == h->h) ? h->h2 : h->h;
+        const int rc = launch_gemv<WT, KVT, D, DM::R1, DM::U_QKV, B, IN_LN_PART, EPI_QKV, 4, true>(a, st);
+        h->hc = a.xout;
+        return rc;
+      }
+    }
+  }
   return launch_gemv<WT, KVT, D, DM::R1, DM::U_QKV, B, IN_LN, EPI_QKV, 4, DM::XLDS>(a, st);
 }
 
@@ -87,7 +103,7 @@ static int gemv_out(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.bias = A_F32(o.bo);
   a.N = D;
   a.slot0 = slot0;
-  a.out = h->h;
+  a.out = h->hc;
   a.out_stride = D;
   if (h->attn_bucket < NBKT) {  // merge the split-S partials while staging
     static_assert(ATTN_NSP == 4 && NBKT == 8, "merge variant / bucket switch above");
@@ -108,7 +124,7 @@ static int gemv_fc(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.bias = A_F32(o.bfc);
   a.N = 4 * D;
   a.slot0 = slot0;
-  a.xin = h->h;
+  a.xin = h->hc;
   a.out = h->ff;
   a.out_stride = 4 * D;
   return launch_gemv<WT, KVT, D, DM::R1, DM::U_FC, B, IN_LN, EPI_GELU, DM::W_FC, DM::XLDS>(a, st);
@@ -125,7 +141,7 @@ static int gemv_pr(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.N = D;
   a.slot0 = slot0;
   a.xin = h->ff;
-  a.out = h->h;
+  a.out = h->hc;
   a.out_stride = D;
   return launch_gemv_lds<WT, KVT, 4 * D, DM::R4, DM::U_PR, B, EPI_RESID, DM::W_PR>(a, st);
 }
@@ -139,7 +155,7 @@ static int gemv_head(ixtts_gpt* h, int slot0, float* norm_out, hipStream_t st) {
   a.bias = A_F32(h->bhead);
   a.N = h->V;
   a.slot0 = slot0;
-  a.xin = h->h;
+  a.xin = h->hc;
   a.ln_w = A_F32(h->lnf_w);
   a.ln_b = A_F32(h->lnf_b);
   a.out = h->logits;
@@ -151,6 +167,7 @@ static int gemv_head(ixtts_gpt* h, int slot0, float* norm_out, hipStream_t st) {
 template <typename WT, typename KVT, int D, int B>
 static int forward_layers(ixtts_gpt* h, int slot0, hipStream_t st) {
   const size_t lstride = (size_t)h->slots * D * h->smax * sizeof(KVT);
+  h->hc = h->h;  // the sampler / prefill leave the token's embedding here; fused-MLP layers alternate between h and h2
   for (int l = 0; l < h->L; ++l) {
     IX_TRY((gemv_qkv<WT, KVT, D, B>(h, l, slot0, st)));
     const void* kcl = (uint8_t*)h->kc + l * lstride;
@@ -178,6 +195,15 @@ static int forward_layers(ixtts_gpt* h, int slot0, hipStream_t st) {
                          h->H, slot0, D, h->att, 1 IXTTS_TRACE_ARG);
     }
     IX_TRY((gemv_out<WT, KVT, D, B>(h, l, slot0, st)));
+    if constexpr (std::is_same<WT, bf16>::value && D == MLP_D) {
+      if (h->mlp_fused && l + 1 < h->L) {  // (the last layer stays split: the head reads a finished residual stream)
+        const LayerOff& o = h->lo[l];
+        hipLaunchKernelGGL((mlp_fused_kernel<B>), dim3(256), dim3(64 * MLP_WAVES), 0, st, reinterpret_cast<const bf16*>(A_PTR(o.wfc)), (const float*)h->hc,
+                           (const float*)A_F32(o.bfc), h->ff, reinterpret_cast<const bf16*>(h->wprx) + (size_t)l * MLP_D * MLP_FF, h->mlp_part,
+                           h->mlp_ctr + (size_t)l * MLP_CTR_STRIDE, h->mlp_ctr + (size_t)(h->L - 1) * MLP_CTR_STRIDE, slot0, h->slots);
+        continue;
+      }
+    }
     IX_TRY((gemv_fc<WT, KVT, D, B>(h, l, slot0, st)));
     IX_TRY((gemv_pr<WT, KVT, D, B>(h, l, slot0, st)));
   }
@@ -330,6 +356,8 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   if (hipMalloc(&h->kc, kvb) != hipSuccess || hipMalloc(&h->vc, kvb) != hipSuccess) return fail("kv cache");
   bool ok = true;
   ok &= hipMalloc(&h->h, (size_t)S * D * 4) == hipSuccess;
+  ok &= hipMalloc(&h->h2, (size_t)S * D * 4) == hipSuccess;
+  h->hc = h->h;
   ok &= hipMalloc(&h->q, (size_t)S * D * 4) == hipSuccess;
   ok &= hipMalloc(&h->ff, (size_t)S * FF * 4) == hipSuccess;
   ok &= hipMalloc(&h->att, (size_t)S * D * 4) == hipSuccess;
@@ -450,6 +478,55 @@ static int fold_all(ixtts_gpt* h) {
   return IXTTS_OK;
 }
 
+// Fused MLP path (mlp_fused_kernel), opt-in with IXTTS_MLP=fused: needs bf16 weights at model_dim 1280, room for the per-XCD
+// copy of c_proj (315 MB), and workgroups dealt round-robin over the 8 XCDs -- probed here with HW_REG_XCC_ID.  Measured r01
+// (profiles/r01_spikes.md): the launch it saves per layer is mostly paid back by the next kernel summing 8 partial vectors
+// (-1.7 % per step at B=2, nothing at B=1), so the split FC / MLP-out kernels stay the default.  Called once the arena holds
+// the final weights.
+static int derive_fused_mlp(ixtts_gpt* h) {
+  h->mlp_fused = false;
+  static const bool dbg = getenv("IXTTS_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "[ixtts] fused MLP: esize %zu D %d FF %d L %d\n", h->esize, h->D, h->FF, h->L);
+  if (h->esize != 2 || h->D != MLP_D || h->FF != MLP_FF || h->L < 2) return IXTTS_OK;
+  const char* mode = getenv("IXTTS_MLP");
+  if (!mode || strcmp(mode, "fused")) return IXTTS_OK;
+  IX_HIP(hipDeviceSynchronize());  // (a broadcast into the arena may still be in flight on another stream)
+  const size_t per_layer = (size_t)MLP_D * MLP_FF * sizeof(bf16);
+  if (!h->wprx) {
+    bool ok = hipMalloc(&h->wprx, per_layer * (h->L - 1)) == hipSuccess;
+    ok = ok && hipMalloc(&h->mlp_part, (size_t)MLP_XCDS * h->slots * MLP_D * 4) == hipSuccess;
+    ok = ok && hipMalloc(&h->mlp_ctr, ((size_t)h->L * MLP_CTR_STRIDE + 4096) * 4) == hipSuccess;  // (+ room for the developer arrival log)
+    if (!ok) {
+      set_error("gpt: allocation failed (fused MLP tables): %s", hipGetErrorString(hipGetLastError()));
+      return IXTTS_ERR_NOMEM;
+    }
+  }
+  IX_HIP(hipMemset(h->mlp_ctr, 0, ((size_t)h->L * MLP_CTR_STRIDE + 4096) * 4));
+  IX_HIP(hipMemset(h->mlp_part, 0, (size_t)MLP_XCDS * h->slots * MLP_D * 4));
+  // XCD placement probe (a few launches of the decode grid): workgroups must be dealt round-robin over the 8 XCDs, from any start
+  unsigned* map = reinterpret_cast<unsigned*>(h->mlp_part);  // (scratch; cleared again below)
+  bool dealt = true;
+  for (int i = 0; i < 8 && dealt; ++i) {
+    hipLaunchKernelGGL(mlp_xcc_probe_kernel, dim3(256), dim3(64 * MLP_WAVES), 0, 0, map);
+    if (i & 1) hipLaunchKernelGGL(mlp_xcc_probe_kernel, dim3(3), dim3(64), 0, 0, map + 256);  // shift the dealer's start
+    unsigned m[256];
+    IX_HIP(hipMemcpy(m, map, sizeof(m), hipMemcpyDeviceToHost));
+    for (int w = 0; w < 256; ++w) dealt = dealt && m[w] < 8u && m[w] == ((m[0] + (unsigned)w) & 7u);
+    if (dbg) fprintf(stderr, "[ixtts] fused MLP: probe %d: workgroup 0 on XCD %u, round-robin %s\n", i, m[0], dealt ? "yes" : "NO");
+  }
+  IX_HIP(hipMemset(h->mlp_part, 0, (size_t)MLP_XCDS * h->slots * MLP_D * 4));
+  if (!dealt) return IXTTS_OK;  // keep the split kernels
+  constexpr size_t G = (size_t)MLP_XCDS * MLP_D * MLP_SLICE / 8;
+  for (int l = 0; l + 1 < h->L; ++l)
+    hipLaunchKernelGGL(mlp_repack_pr_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<const bf16*>(A_PTR(h->lo[l].wpr)),
+                       reinterpret_cast<bf16*>(h->wprx) + (size_t)l * MLP_D * MLP_FF);
+  IX_HIP(hipDeviceSynchronize());
+  IX_HIP(hipGetLastError());
+  h->mlp_fused = true;
+  if (dbg) fprintf(stderr, "[ixtts] fused MLP: on\n");
+  return IXTTS_OK;
+}
+
 extern "C" int ixtts_gpt_finalize(ixtts_gpt* h) {
   IX_ARG(h, "gpt_finalize: null handle");
   if (h->finalized) return IXTTS_OK;
@@ -463,7 +540,7 @@ extern "C" int ixtts_gpt_finalize(ixtts_gpt* h) {
   hipFree(h->stage);
   h->stage = nullptr;
   h->finalized = true;
-  return IXTTS_OK;
+  return derive_fused_mlp(h);
 }
 
 extern "C" int ixtts_gpt_arena(ixtts_gpt* h, void** ptr, size_t* bytes) {
@@ -481,7 +558,7 @@ extern "C" int ixtts_gpt_adopt_arena(ixtts_gpt* h) {
     h->stage = nullptr;
   }
   h->finalized = true;
-  return IXTTS_OK;
+  return derive_fused_mlp(h);
 }
 
 #define NEED_READY(h, who)                                       \
@@ -527,6 +604,7 @@ extern "C" int ixtts_gpt_prefill(ixtts_gpt* h, int b, const float* embeds, int n
                      (const float*)(A_F32(h->mel_emb) + (size_t)h->cfg.start_mel_token * D), (const float*)A_F32(h->mel_pos), D);
   IX_TRY(forward_rows(h, b, T, n_left_pad, n_left_pad, st));
   IX_HIP(hipMemcpyAsync(h->h + (size_t)b * D, h->rx + (size_t)(T - 1) * D, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
+  h->hc = h->h;
   IX_TRY(do_head(h, 1, b, nullptr, st));
   IX_HIP(hipGetLastError());
   return IXTTS_OK;
@@ -745,11 +823,42 @@ extern "C" int ixtts_gpt_beam_read(ixtts_gpt* h, int max_new, int32_t* ids, int 
   return IXTTS_OK;
 }
 
+// The fused MLP kernel never waits forever for its XCD's workgroups: after ~13 ms it leaves a mark and goes on with what it
+// has.  Results of such a run are wrong; every read of results checks the mark and fails loudly.
+static int check_mlp_handoff(ixtts_gpt* h) {
+  if (!h->mlp_fused) return IXTTS_OK;
+  unsigned m[1 + MLP_XCDS];
+  IX_HIP(hipMemcpy(m, h->mlp_ctr + (size_t)(h->L - 1) * MLP_CTR_STRIDE, sizeof(m), hipMemcpyDeviceToHost));
+#ifdef IXTTS_MLP_LOG
+  {  // developer timeline of the layer-10 kernel's last run: per workgroup entry / ff done / arrived / released / end
+    static unsigned long long lg[256 * 6];
+    IX_HIP(hipMemcpy(lg, h->mlp_ctr + (size_t)h->L * MLP_CTR_STRIDE, sizeof(lg), hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (int i = 0; i < 256; ++i)
+      if (lg[6 * i + 1] && lg[6 * i + 1] < t0) t0 = lg[6 * i + 1];
+    double s[5] = {0, 0, 0, 0, 0}, mx[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 256; ++i)
+      for (int k = 0; k < 5; ++k) {
+        const double v = (double)(lg[6 * i + 1 + k] - t0) * 0.01;
+        s[k] += v / 256;
+        mx[k] = v > mx[k] ? v : mx[k];
+      }
+    fprintf(stderr, "[ixtts] fused MLP timeline us (mean / max over workgroups): entry %.2f/%.2f  ff done %.2f/%.2f  arrived %.2f/%.2f  released %.2f/%.2f  end %.2f/%.2f\n",
+            s[0], mx[0], s[1], mx[1], s[2], mx[2], s[3], mx[3], s[4], mx[4]);
+  }
+#endif
+  if (m[0] == 0) return IXTTS_OK;
+  set_error("gpt: the fused MLP kernel's hand-off inside an XCD timed out (%u workgroups; arrivals seen per XCD: %u %u %u %u %u %u %u %u of 32); unset IXTTS_MLP",
+            m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8]);
+  return IXTTS_ERR_STATE;
+}
+
 extern "C" int ixtts_gpt_read(ixtts_gpt* h, int b, int32_t* ids, int cap, int* n_ids, int* finished, void* stream) {
   NEED_READY(h, "gpt_read");
   IX_ARG(b >= 0 && b < h->cfg.max_batch && ids && n_ids && finished && cap >= 0, "gpt_read: bad argument");
   hipStream_t st = (hipStream_t)stream;
   IX_HIP(hipStreamSynchronize(st));
+  IX_TRY(check_mlp_handoff(h));
   int gc = 0, fin = 0;
   IX_HIP(hipMemcpy(&gc, h->gen_count + b, 4, hipMemcpyDeviceToHost));
   IX_HIP(hipMemcpy(&fin, h->finished + b, 4, hipMemcpyDeviceToHost));
@@ -845,7 +954,7 @@ extern "C" int ixtts_gpt_destroy(ixtts_gpt* h) {
   void* ptrs[] = {h->arena, h->stage, h->kc, h->vc, h->h, h->q, h->ff, h->att, h->part, h->logits, h->rowbuf, h->cur_len, h->gen_count,
                   h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->probs, h->scratch, h->beam_scores, h->hyp_score, h->hyp_worst, h->beam_src, h->hyp_len,
                   h->n_hyp, h->beam_done, h->beam_forced_flag, h->beam_forced, h->hyp_tok, h->beam_cand_v, h->beam_cand_i, h->beam_cand_n,
-                  h->rx, h->rxn, h->rq, h->ratt, h->rff};
+                  h->rx, h->rxn, h->rq, h->ratt, h->rff, h->h2, h->wprx, h->mlp_part, h->mlp_ctr};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete h;

@@ -64,7 +64,10 @@ struct TraceScope {
 #define IXTTS_TRACE_SEQ 0
 #endif
 
-enum { IN_LN = 0, IN_LN2 = 1, IN_PLAIN = 2, IN_ATTN2 = 4, IN_ATTN4 = 5 };  // IN_ATTNn: merge of n split-S attention partials
+enum { IN_LN = 0, IN_LN2 = 1, IN_PLAIN = 2, IN_ATTN2 = 4, IN_ATTN4 = 5, IN_LN_PART = 6 };  // IN_ATTNn: merge of n split-S attention partials
+// IN_LN_PART: the residual stream is h + bias + the 8 per-XCD partial sums the fused MLP kernel of the previous layer left
+// (mlp_fused_kernel); the first workgroup writes the completed h back for the later residual add
+constexpr int MLP_XCDS = 8;
 
 // split-S attention partials: per (slot, head, split) [m, l, pad, pad, acc[64]] (acc 16-byte aligned)
 constexpr int PART_STRIDE = 4 + 64;
@@ -89,6 +92,8 @@ struct GemvArgs {
   int smax;             // KV capacity per (slot, head)
   int heads;
   float* norm_out;      // optional (IN_LN2): ln_f output BEFORE the folded final_norm gain, unused
+  unsigned* aux;        // EPI_QKV: fused-MLP arrival counters to clear (or null)
+  float* xout;          // IN_LN_PART: where the completed residual stream is published
 };
 
 // 16 bytes of weights per lane per load, kept RAW in registers until the dot product.
@@ -208,13 +213,17 @@ __device__ __forceinline__ void block_sum(float (&s)[B], float* red, int wave, i
 template <typename WT, int K, int ROWS, int UNITS, int B, int INP, int EPI, typename KVT, int WPB = 4, bool XLDS = false>
 __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, const float* xin, const float* bias, float* out, int N, int slot0, int out_stride, int smax,
                                                         void* kcache, void* vcache, const int* cur_len, int heads, int nsplit,
-                                                        const float* ln_w, const float* ln_b IXTTS_TRACE_PARAM) {
+                                                        const float* ln_w, const float* ln_b, unsigned* aux, float* xout IXTTS_TRACE_PARAM) {
   // scalar kernel arguments (not a by-value struct): the first 16 dwords are preloaded into SGPRs at wave launch
   // (-amdgpu-kernarg-preload-count), so the first loads do not wait for a kernarg round trip
   GemvArgs a;
   a.wt = wt; a.xin = xin; a.bias = bias; a.out = out; a.N = N; a.slot0 = slot0; a.out_stride = out_stride; a.smax = smax;
   a.kcache = kcache; a.vcache = vcache; a.cur_len = cur_len; a.heads = heads; a.nsplit = nsplit; a.ln_w = ln_w; a.ln_b = ln_b;
   a.norm_out = nullptr;
+  // EPI_QKV: `aux` = the per-XCD arrival counters of this layer's fused MLP kernel, cleared here (two kernel boundaries
+  // ahead of their use).  IN_LN_PART: ln_w = the partials [8][slots][K], ln_b = the bias to add, nsplit = slots, xout = the
+  // OTHER residual buffer, where the completed stream is published (in place would race with the workgroups still reading).
+  if (EPI == EPI_QKV && aux != nullptr && blockIdx.x == 0 && threadIdx.x < MLP_XCDS) aux[threadIdx.x * 32] = 0u;
   TraceScope trace(EPI, IXTTS_TRACE_SEQ);
   constexpr int VEC = WVec<WT>::VEC;
   constexpr int PER = 64 * VEC;       // elements per wave-load
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, cons
   static_assert(K % VEC == 0 && K % 4 == 0, "row length must be a multiple of the vector width");
   static_assert(XLDS || INP == IN_PLAIN, "LayerNorm / split-S merge inputs are staged by the workgroup (XLDS)");
   constexpr int NSP = INP == IN_ATTN2 ? 2 : (INP == IN_ATTN4 ? 4 : 1);
-  constexpr int NPASS = INP == IN_LN ? 1 : (INP == IN_LN2 ? 2 : 0);
+  constexpr int NPASS = (INP == IN_LN || INP == IN_LN_PART) ? 1 : (INP == IN_LN2 ? 2 : 0);
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -236,6 +245,7 @@ __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, cons
   f32x2 xr[B][NL][VEC / 2];
   float4 xs4[XLDS ? XV : 1];             // staged element i of this thread: float4 number threadIdx.x + i*NT of [B][K]
   float4 lw4[NPASS == 2 ? XV : 1], lb4[NPASS == 2 ? XV : 1];
+  float4 pbias4[INP == IN_LN_PART ? XV : 1], ppart4[INP == IN_LN_PART ? XV : 1][MLP_XCDS];
   float2 pml[NSP > 1 ? XV : 1][NSP];     // split-S partials: (m, l) and the accumulator slice
   float4 pac[NSP > 1 ? XV : 1][NSP];
   if constexpr (XLDS && NSP == 1) {
@@ -247,6 +257,13 @@ __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, cons
       if constexpr (NPASS == 2) {  // explicit affine of the first norm (ln_f); the last norm's affine is folded into W
         lw4[i] = *reinterpret_cast<const float4*>(a.ln_w + (idx % K4) * 4);
         lb4[i] = *reinterpret_cast<const float4*>(a.ln_b + (idx % K4) * 4);
+      }
+      if constexpr (INP == IN_LN_PART) {
+        const int b = idx / K4, k0 = (idx % K4) * 4;
+        pbias4[i] = *reinterpret_cast<const float4*>(a.ln_b + k0);
+#pragma unroll
+        for (int x = 0; x < MLP_XCDS; ++x)
+          ppart4[i][x] = *reinterpret_cast<const float4*>(a.ln_w + ((size_t)x * a.nsplit + a.slot0 + b) * K + k0);
       }
     }
   } else if constexpr (XLDS) {
@@ -327,6 +344,22 @@ __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, cons
         }
         const float inv = 1.0f / L;
         xs4[i] = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+      }
+    }
+    if constexpr (INP == IN_LN_PART) {
+      // complete the residual stream: h += bias + sum over the XCDs' partials (fixed order), and publish it once
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        float4 t = xs4[i];
+        t.x += pbias4[i].x; t.y += pbias4[i].y; t.z += pbias4[i].z; t.w += pbias4[i].w;
+#pragma unroll
+        for (int x = 0; x < MLP_XCDS; ++x) {
+          t.x += ppart4[i][x].x; t.y += ppart4[i][x].y; t.z += ppart4[i][x].z; t.w += ppart4[i][x].w;
+        }
+        xs4[i] = t;
+        const int idx = threadIdx.x + i * NT;
+        if (blockIdx.x == 0 && (X4 % NT == 0 || idx < X4))
+          *reinterpret_cast<float4*>(xout + (size_t)a.slot0 * K + (size_t)idx * 4) = t;
       }
     }
 #pragma unroll
@@ -442,7 +475,7 @@ __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, cons
 template <typename WT, int K, int ROWS, int UNITS, int B, int EPI, typename KVT, int WPB = 4>
 __global__ __launch_bounds__(64 * WPB) void gemv_lds_kernel(const void* wt, const float* xin, const float* bias, float* out, int N, int slot0, int out_stride, int smax,
                                                         void* kcache, void* vcache, const int* cur_len, int heads, int nsplit,
-                                                        const float* ln_w, const float* ln_b IXTTS_TRACE_PARAM) {
+                                                        const float* ln_w, const float* ln_b, unsigned* aux, float* xout IXTTS_TRACE_PARAM) {
   // scalar kernel arguments (not a by-value struct): the first 16 dwords are preloaded into SGPRs at wave launch
   // (-amdgpu-kernarg-preload-count), so the first loads do not wait for a kernarg round trip
   GemvArgs a;
@@ -547,6 +580,285 @@ __global__ __launch_bounds__(64 * WPB) void gemv_lds_kernel(const void* wt, cons
     gemv_epilogue<K, ROWS, B, EPI, KVT>(a, lane, unit, tot, pre_bias[u], pre_res[u], 0);
   }
   trace.end();
+}
+
+// ------------------------------------------------------------------------------------
+// Fused MLP of one decode step (bf16 weights, model_dim 1280): LN2 + c_fc + gelu + c_proj in ONE launch, with the hand-off
+// between the two matrices made inside each XCD instead of across a kernel boundary.
+//
+// 256 workgroups x 5 waves, one per CU.  The dispatcher deals workgroups round-robin over the 8 XCDs starting wherever the
+// previous dispatch stopped, so workgroup i runs on XCD (i + c) % 8 with c unknown: the kernel reads its XCD from
+// HW_REG_XCC_ID and takes j = i / 8 as its index among that XCD's 32 workgroups (8 consecutive workgroups sit on 8
+// different XCDs; the engine checks this dealing once, with a probe).  XCD x
+// owns the 640 ff rows [640 x, 640 x + 640): its 32 workgroups compute them (20 rows each, exactly the FC GEMV above),
+// publish them through the XCD's L2 -- stores, s_waitcnt, one WORKGROUP-scope atomic per workgroup on the XCD's counter;
+// the atomics execute in that L2 and the poll is an atomic too, so no line can be stale in an L1 -- and, once all 32
+// have arrived (0.7-0.8 us, tools/spike_xcdsync.hip; an agent-scope barrier costs 4.4 us, a kernel boundary ~3 us of
+// exit + launch + first-operand latency), each multiplies the XCD's K-slice of c_proj (weights repacked per XCD, loaded into
+// registers at entry together with the FC rows) for 40 of the 1280 outputs.  What leaves the kernel are 8 partial sums per
+// output, [xcd][slot][1280]; the next layer's QKV kernel adds them to the residual stream while staging (IN_LN_PART).
+// Saves one launch per layer and the second activation round trip (FC 5.4 + MLP-out 5.3 us -> 6.x us).
+constexpr int MLP_D = 1280, MLP_FF = 5120, MLP_WAVES = 5, MLP_SLICE = MLP_FF / MLP_XCDS, MLP_ROWS_OUT = MLP_D / 32, MLP_KSUB = MLP_SLICE / MLP_WAVES;
+static_assert(MLP_SLICE == 640 && MLP_ROWS_OUT == 40 && MLP_KSUB == 128, "partition of the fused MLP");
+constexpr unsigned MLP_SPIN_MAX = 1u << 15;  // x ~0.4 us per poll: ~13 ms, three orders of magnitude above a healthy hand-off
+constexpr int MLP_CTR_STRIDE = MLP_XCDS * 32;  // uints per layer: one 128-byte line per XCD (the never-fused last layer's block holds the timeout mark)
+
+// sum over the 16 lanes of a DPP row; every lane of the row gets it (fixed order)
+__device__ __forceinline__ float group_sum16(float v) {
+  v += dpp_take<0xB1, 0xf, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_take<0x4E, 0xf, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_take<0x141, 0xf, 0xf>(v);  // row_half_mirror
+  v += dpp_take<0x140, 0xf, 0xf>(v);  // row_mirror
+  return v;
+}
+
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xf;
+}
+
+// out[x][n][c] = in[n][640 x + c]   (c_proj weights [1280][5120] -> one contiguous [1280][640] block per XCD)
+static __global__ void mlp_repack_pr_kernel(const bf16* __restrict__ in, bf16* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte granule of the output
+  constexpr size_t G = (size_t)MLP_XCDS * MLP_D * MLP_SLICE / 8;
+  if (i >= G) return;
+  const size_t e = i * 8;
+  const int c = (int)(e % MLP_SLICE);
+  const int n = (int)((e / MLP_SLICE) % MLP_D);
+  const int x = (int)(e / ((size_t)MLP_SLICE * MLP_D));
+  reinterpret_cast<uint4*>(out)[i] = *reinterpret_cast<const uint4*>(in + (size_t)n * MLP_FF + (size_t)x * MLP_SLICE + c);
+}
+
+// map[i] = XCD of workgroup i
+static __global__ void mlp_xcc_probe_kernel(unsigned* map) {
+  if (threadIdx.x == 0) map[blockIdx.x] = xcc_id();
+}
+
+template <int B>
+__global__ __launch_bounds__(64 * MLP_WAVES) void mlp_fused_kernel(const bf16* __restrict__ wfc, const float* __restrict__ hin, const float* __restrict__ bfc,
+                                                                   float* ff, const bf16* __restrict__ wprx, float* __restrict__ part,
+                                                                   unsigned* ctr, unsigned* mark, int slot0, int slots) {
+  constexpr int K = MLP_D, ROWS = 2, UNITS = 2, VEC = 8, PER = 64 * VEC, NL = ROWS * K / PER, WPB = MLP_WAVES, NT = 64 * WPB;
+  constexpr int K4 = K / 4, X4 = B * K4, XV = (X4 + NT - 1) / NT;
+  constexpr int NPR = MLP_ROWS_OUT / 4;  // c_proj loads per lane: 4 rows x 16 lanes per wave-load
+  __shared__ __attribute__((aligned(16))) float xsh[B * K];
+  __shared__ float red[2 * WPB * B];
+  __shared__ float prs[WPB][MLP_ROWS_OUT][B];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xcd = (int)xcc_id() & 7, j = blockIdx.x >> 3;
+#ifdef IXTTS_MLP_LOG
+  const unsigned long long t_entry = wall_clock64();
+  unsigned long long t_ff = 0, t_arrive = 0, t_rel = 0;
+  const bool logging = ctr == mark - (size_t)(gridDim.y + 12) * MLP_CTR_STRIDE;  // layer 10 of 24
+#endif
+  const int unit0 = ((xcd * 32 + j) * WPB + wave) * UNITS;  // ff rows 640 xcd + 20 j + 4 wave ...
+
+  // ---- 1. activations
+  float4 xs4[XV];
+  const float* xbase = hin + (size_t)slot0 * K;
+#pragma unroll
+  for (int i = 0; i < XV; ++i) {
+    const int idx = min((int)threadIdx.x + i * NT, X4 - 1);
+    xs4[i] = *reinterpret_cast<const float4*>(xbase + (size_t)idx * 4);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- 2. bias of the ff rows this lane will write
+  float pre_bias[UNITS];
+  const int elane = min(lane, ROWS * B - 1);
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u) pre_bias[u] = bfc[(unit0 + u) * ROWS + elane / B];
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- 3. the c_fc rows of this workgroup (20)
+  uint4 wraw[UNITS][NL];
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u) {
+    const bf16* base = wfc + (size_t)(unit0 + u) * ROWS * K;
+#pragma unroll
+    for (int jj = 0; jj < NL; ++jj) wraw[u][jj] = *reinterpret_cast<const uint4*>(base + jj * PER + lane * VEC);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- 4. LayerNorm (gain / bias folded into c_fc) -> LDS, as in gemv_reg_kernel
+  {
+    float s[B], q[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) s[b] = 0.f;
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int idx = threadIdx.x + i * NT;
+      const int sl = (X4 % NT == 0 || idx < X4) ? idx / K4 : B;
+      const float v = (xs4[i].x + xs4[i].y) + (xs4[i].z + xs4[i].w);
+#pragma unroll
+      for (int b = 0; b < B; ++b) s[b] += (sl == b) ? v : 0.f;
+    }
+    block_sum<B, WPB>(s, red, wave, lane);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      s[b] *= (1.0f / K);
+      q[b] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int idx = threadIdx.x + i * NT;
+      const int sl = (X4 % NT == 0 || idx < X4) ? idx / K4 : B;
+      float mean = 0.f;
+#pragma unroll
+      for (int b = 0; b < B; ++b) mean = (sl == b) ? s[b] : mean;
+      xs4[i].x -= mean; xs4[i].y -= mean; xs4[i].z -= mean; xs4[i].w -= mean;
+      const float v = fmaf(xs4[i].x, xs4[i].x, xs4[i].y * xs4[i].y) + fmaf(xs4[i].z, xs4[i].z, xs4[i].w * xs4[i].w);
+#pragma unroll
+      for (int b = 0; b < B; ++b) q[b] += (sl == b) ? v : 0.f;
+    }
+    block_sum<B, WPB>(q, red + WPB * B, wave, lane);
+#pragma unroll
+    for (int b = 0; b < B; ++b) q[b] = 1.0f / sqrtf(q[b] * (1.0f / K) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int idx = threadIdx.x + i * NT;
+      const int sl = (X4 % NT == 0 || idx < X4) ? idx / K4 : B;
+      float rstd = 0.f;
+#pragma unroll
+      for (int b = 0; b < B; ++b) rstd = (sl == b) ? q[b] : rstd;
+      xs4[i].x *= rstd; xs4[i].y *= rstd; xs4[i].z *= rstd; xs4[i].w *= rstd;
+      if (X4 % NT == 0 || idx < X4) *reinterpret_cast<float4*>(xsh + idx * 4) = xs4[i];
+    }
+  }
+  __syncthreads();
+  // the c_proj slice goes out now -- behind the c_fc rows, which are about to be used, and under the dots, the stores and the
+  // hand-off (issued at entry it shared the first 3 us of bandwidth with them: the ff rows were ready 1.3 us later)
+  uint4 praw[NPR];
+  {
+    const bf16* base = wprx + ((size_t)xcd * MLP_D + (size_t)j * MLP_ROWS_OUT + (lane >> 4)) * MLP_SLICE + wave * MLP_KSUB + (lane & 15) * VEC;
+#pragma unroll
+    for (int i = 0; i < NPR; ++i) praw[i] = *reinterpret_cast<const uint4*>(base + (size_t)(4 * i) * MLP_SLICE);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- 5. c_fc rows: packed fp32 dots, gelu, ff to memory (this XCD's L2)
+  {
+    f32x2 xr[B][NL][VEC / 2];
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int jj = 0; jj < NL; ++jj) {
+        const int k0 = (jj * PER + lane * VEC) % K;
+#pragma unroll
+        for (int v4 = 0; v4 < VEC / 4; ++v4) {
+          const float4 t = *reinterpret_cast<const float4*>(xsh + b * K + k0 + v4 * 4);
+          xr[b][jj][v4 * 2] = f32x2{t.x, t.y};
+          xr[b][jj][v4 * 2 + 1] = f32x2{t.z, t.w};
+        }
+      }
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+      float acc[ROWS][B];
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < NL; ++jj) {
+        const int row = (jj * PER + lane * VEC) / K;
+        f32x2 w2[VEC / 2];
+        unpack2<bf16>(wraw[u][jj], w2);
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          f32x2 d2 = w2[0] * xr[b][jj][0];
+#pragma unroll
+          for (int v = 1; v < VEC / 2; ++v) d2 = __builtin_elementwise_fma(w2[v], xr[b][jj][v], d2);
+          const float d = d2.x + d2.y;
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) acc[r][b] += (row == r) ? d : 0.f;
+        }
+      }
+      float mine = 0.f;
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          const float t = wave_sum(acc[r][b]);
+          mine = (lane == r * B + b) ? t : mine;
+        }
+      if (lane < ROWS * B) {
+        const int r = lane / B, b = lane % B;
+        ff[(size_t)(slot0 + b) * MLP_FF + (unit0 + u) * ROWS + r] = gelu_new_f(mine + pre_bias[u]);
+      }
+    }
+  }
+  // ---- 6. hand-off inside the XCD
+#ifdef IXTTS_MLP_LOG
+  t_ff = wall_clock64();
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's ff stores have reached L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* c = ctr + xcd * 32;
+    const unsigned ticket = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef IXTTS_MLP_LOG
+    t_arrive = wall_clock64();
+#endif
+    (void)ticket;
+    // the poll must be a real read-modify-write (it executes at L2): `fetch_or(c, 0)` is folded into a plain load, which
+    // spins on a stale L1 line.  A compare-exchange that can never succeed returns the current value and is not folded.
+    unsigned n = 0, seen;
+    auto poll = [&]() {
+      unsigned expect = 0xffffffffu;
+      __hip_atomic_compare_exchange_strong(c, &expect, 0xffffffffu, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return expect;
+    };
+    while ((seen = poll()) < 32u) {
+      if (++n > MLP_SPIN_MAX) {  // never on a healthy run: leave a mark (and what was seen) instead of hanging the queue
+        __hip_atomic_fetch_add(mark, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mark + 1 + xcd, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(mark + 16 + xcd, ticket + 1000u * (unsigned)slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+#ifdef IXTTS_MLP_LOG
+  if (threadIdx.x == 0) t_rel = wall_clock64();
+#endif
+  __syncthreads();
+  asm volatile("" ::: "memory");
+  // ---- 7. the c_proj partials: every lane reads its 8 columns of this XCD's ff slice straight from L2 (first touch by this
+  //         CU in this launch: cannot be stale)
+  {
+    f32x2 xp[B][VEC / 2];
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int v4 = 0; v4 < VEC / 4; ++v4) {
+        const float4 t = *reinterpret_cast<const float4*>(ff + (size_t)(slot0 + b) * MLP_FF + xcd * MLP_SLICE + wave * MLP_KSUB + (lane & 15) * VEC + v4 * 4);
+        xp[b][v4 * 2] = f32x2{t.x, t.y};
+        xp[b][v4 * 2 + 1] = f32x2{t.z, t.w};
+      }
+#pragma unroll
+    for (int i = 0; i < NPR; ++i) {
+      f32x2 w2[VEC / 2];
+      unpack2<bf16>(praw[i], w2);
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        f32x2 d2 = w2[0] * xp[b][0];
+#pragma unroll
+        for (int v = 1; v < VEC / 2; ++v) d2 = __builtin_elementwise_fma(w2[v], xp[b][v], d2);
+        const float d = group_sum16(d2.x + d2.y);
+        if ((lane & 15) == 0) prs[wave][4 * i + (lane >> 4)][b] = d;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < MLP_ROWS_OUT * B) {
+    const int r = threadIdx.x / B, b = threadIdx.x % B;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) t += prs[w][r][b];
+    part[((size_t)xcd * slots + slot0 + b) * MLP_D + j * MLP_ROWS_OUT + r] = t;
+  }
+#ifdef IXTTS_MLP_LOG
+  if (threadIdx.x == 0 && logging) {
+    unsigned long long* lg = reinterpret_cast<unsigned long long*>(mark + MLP_CTR_STRIDE) + blockIdx.x * 6;
+    lg[0] = xcd; lg[1] = t_entry; lg[2] = t_ff; lg[3] = t_arrive; lg[4] = t_rel; lg[5] = wall_clock64();
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------
