@@ -169,9 +169,9 @@ static int forward_layers(ixtts_gpt* h, int slot0, hipStream_t st) {
   const size_t lstride = (size_t)h->slots * D * h->smax * sizeof(KVT);
   h->hc = h->h;  // the sampler / prefill leave the token's embedding here; fused-MLP layers alternate between h and h2
   for (int l = 0; l < h->L; ++l) {
-    IX_TRY((gemv_qkv<WT, KVT, D, B>(h, l, slot0, st)));
     const void* kcl = (uint8_t*)h->kc + l * lstride;
     const void* vcl = (uint8_t*)h->vc + l * lstride;
+    IX_TRY((gemv_qkv<WT, KVT, D, B>(h, l, slot0, st)));
     if (h->attn_bucket < NBKT) {
       constexpr int F = 8 / KVLayout<KVT>::PPW;  // fp32 cache: half the keys per wave-load, twice the blocks
       const dim3 grid(h->H, ATTN_NSP, B);
@@ -200,7 +200,7 @@ static int forward_layers(ixtts_gpt* h, int slot0, hipStream_t st) {
         const LayerOff& o = h->lo[l];
         hipLaunchKernelGGL((mlp_fused_kernel<B>), dim3(256), dim3(64 * MLP_WAVES), 0, st, reinterpret_cast<const bf16*>(A_PTR(o.wfc)), (const float*)h->hc,
                            (const float*)A_F32(o.bfc), h->ff, reinterpret_cast<const bf16*>(h->wprx) + (size_t)l * MLP_D * MLP_FF, h->mlp_part,
-                           h->mlp_ctr + (size_t)l * MLP_CTR_STRIDE, h->mlp_ctr + (size_t)(h->L - 1) * MLP_CTR_STRIDE, slot0, h->slots);
+                           h->mlp_ctr + (size_t)l * MLP_CTR_STRIDE, h->mlp_ctr + (size_t)h->L * MLP_CTR_STRIDE, slot0, h->slots);
         continue;
       }
     }
@@ -478,33 +478,25 @@ static int fold_all(ixtts_gpt* h) {
   return IXTTS_OK;
 }
 
-// Fused MLP path (mlp_fused_kernel), opt-in with IXTTS_MLP=fused: needs bf16 weights at model_dim 1280, room for the per-XCD
-// copy of c_proj (315 MB), and workgroups dealt round-robin over the 8 XCDs -- probed here with HW_REG_XCC_ID.  Measured r01
-// (profiles/r01_spikes.md): the launch it saves per layer is mostly paid back by the next kernel summing 8 partial vectors
-// (-1.7 % per step at B=2, nothing at B=1), so the split FC / MLP-out kernels stay the default.  Called once the arena holds
-// the final weights.
+// The launch fused on the XCD-local hand-off, opt-in: IXTTS_MLP=fused (mlp_fused_kernel: LN2 + c_fc + gelu + c_proj, 315 MB
+// for the per-XCD copy of c_proj; measured -1.7 % per step at B=2 and nothing at B=1, profiles/r01_spikes.md).  It needs
+// bf16 weights at model_dim 1280 and workgroups dealt round-robin over the 8 XCDs -- probed here with HW_REG_XCC_ID;
+// anything else keeps the split kernels.  Called once the arena holds the final weights.
 static int derive_fused_mlp(ixtts_gpt* h) {
   h->mlp_fused = false;
   static const bool dbg = getenv("IXTTS_DEBUG") != nullptr;
-  if (dbg) fprintf(stderr, "[ixtts] fused MLP: esize %zu D %d FF %d L %d\n", h->esize, h->D, h->FF, h->L);
   if (h->esize != 2 || h->D != MLP_D || h->FF != MLP_FF || h->L < 2) return IXTTS_OK;
-  const char* mode = getenv("IXTTS_MLP");
-  if (!mode || strcmp(mode, "fused")) return IXTTS_OK;
+  const char* m_mlp = getenv("IXTTS_MLP");
+  if (!m_mlp || strcmp(m_mlp, "fused")) return IXTTS_OK;
   IX_HIP(hipDeviceSynchronize());  // (a broadcast into the arena may still be in flight on another stream)
-  const size_t per_layer = (size_t)MLP_D * MLP_FF * sizeof(bf16);
-  if (!h->wprx) {
-    bool ok = hipMalloc(&h->wprx, per_layer * (h->L - 1)) == hipSuccess;
-    ok = ok && hipMalloc(&h->mlp_part, (size_t)MLP_XCDS * h->slots * MLP_D * 4) == hipSuccess;
-    ok = ok && hipMalloc(&h->mlp_ctr, ((size_t)h->L * MLP_CTR_STRIDE + 4096) * 4) == hipSuccess;  // (+ room for the developer arrival log)
-    if (!ok) {
-      set_error("gpt: allocation failed (fused MLP tables): %s", hipGetErrorString(hipGetLastError()));
-      return IXTTS_ERR_NOMEM;
-    }
+  const size_t ctr_uints = (size_t)h->L * MLP_CTR_STRIDE + 4096;  // per-layer counters, then the time-out mark (+ developer log)
+  if (!h->mlp_ctr && hipMalloc(&h->mlp_ctr, ctr_uints * 4) != hipSuccess) {
+    set_error("gpt: allocation failed (hand-off counters): %s", hipGetErrorString(hipGetLastError()));
+    return IXTTS_ERR_NOMEM;
   }
-  IX_HIP(hipMemset(h->mlp_ctr, 0, ((size_t)h->L * MLP_CTR_STRIDE + 4096) * 4));
-  IX_HIP(hipMemset(h->mlp_part, 0, (size_t)MLP_XCDS * h->slots * MLP_D * 4));
+  IX_HIP(hipMemset(h->mlp_ctr, 0, ctr_uints * 4));
   // XCD placement probe (a few launches of the decode grid): workgroups must be dealt round-robin over the 8 XCDs, from any start
-  unsigned* map = reinterpret_cast<unsigned*>(h->mlp_part);  // (scratch; cleared again below)
+  unsigned* map = h->mlp_ctr + (size_t)h->L * MLP_CTR_STRIDE + 1024;  // (scratch inside the spare region; cleared again below)
   bool dealt = true;
   for (int i = 0; i < 8 && dealt; ++i) {
     hipLaunchKernelGGL(mlp_xcc_probe_kernel, dim3(256), dim3(64 * MLP_WAVES), 0, 0, map);
@@ -512,10 +504,20 @@ static int derive_fused_mlp(ixtts_gpt* h) {
     unsigned m[256];
     IX_HIP(hipMemcpy(m, map, sizeof(m), hipMemcpyDeviceToHost));
     for (int w = 0; w < 256; ++w) dealt = dealt && m[w] < 8u && m[w] == ((m[0] + (unsigned)w) & 7u);
-    if (dbg) fprintf(stderr, "[ixtts] fused MLP: probe %d: workgroup 0 on XCD %u, round-robin %s\n", i, m[0], dealt ? "yes" : "NO");
+    if (dbg) fprintf(stderr, "[ixtts] fused launches: probe %d: workgroup 0 on XCD %u, round-robin %s\n", i, m[0], dealt ? "yes" : "NO");
+  }
+  IX_HIP(hipMemset(h->mlp_ctr, 0, ctr_uints * 4));
+  if (!dealt) return IXTTS_OK;  // keep the split kernels
+  const size_t per_layer = (size_t)MLP_D * MLP_FF * sizeof(bf16);
+  if (!h->wprx) {
+    bool ok = hipMalloc(&h->wprx, per_layer * (h->L - 1)) == hipSuccess;
+    ok = ok && hipMalloc(&h->mlp_part, (size_t)MLP_XCDS * h->slots * MLP_D * 4) == hipSuccess;
+    if (!ok) {
+      set_error("gpt: allocation failed (fused MLP tables): %s", hipGetErrorString(hipGetLastError()));
+      return IXTTS_ERR_NOMEM;
+    }
   }
   IX_HIP(hipMemset(h->mlp_part, 0, (size_t)MLP_XCDS * h->slots * MLP_D * 4));
-  if (!dealt) return IXTTS_OK;  // keep the split kernels
   constexpr size_t G = (size_t)MLP_XCDS * MLP_D * MLP_SLICE / 8;
   for (int l = 0; l + 1 < h->L; ++l)
     hipLaunchKernelGGL(mlp_repack_pr_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<const bf16*>(A_PTR(h->lo[l].wpr)),
@@ -828,11 +830,11 @@ extern "C" int ixtts_gpt_beam_read(ixtts_gpt* h, int max_new, int32_t* ids, int 
 static int check_mlp_handoff(ixtts_gpt* h) {
   if (!h->mlp_fused) return IXTTS_OK;
   unsigned m[1 + MLP_XCDS];
-  IX_HIP(hipMemcpy(m, h->mlp_ctr + (size_t)(h->L - 1) * MLP_CTR_STRIDE, sizeof(m), hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(m, h->mlp_ctr + (size_t)h->L * MLP_CTR_STRIDE, sizeof(m), hipMemcpyDeviceToHost));
 #ifdef IXTTS_MLP_LOG
   {  // developer timeline of the layer-10 kernel's last run: per workgroup entry / ff done / arrived / released / end
     static unsigned long long lg[256 * 6];
-    IX_HIP(hipMemcpy(lg, h->mlp_ctr + (size_t)h->L * MLP_CTR_STRIDE, sizeof(lg), hipMemcpyDeviceToHost));
+    IX_HIP(hipMemcpy(lg, h->mlp_ctr + (size_t)(h->L + 1) * MLP_CTR_STRIDE, sizeof(lg), hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull;
     for (int i = 0; i < 256; ++i)
       if (lg[6 * i + 1] && lg[6 * i + 1] < t0) t0 = lg[6 * i + 1];
@@ -848,7 +850,7 @@ static int check_mlp_handoff(ixtts_gpt* h) {
   }
 #endif
   if (m[0] == 0) return IXTTS_OK;
-  set_error("gpt: the fused MLP kernel's hand-off inside an XCD timed out (%u workgroups; arrivals seen per XCD: %u %u %u %u %u %u %u %u of 32); unset IXTTS_MLP",
+  set_error("gpt: a fused kernel's hand-off inside an XCD timed out (%u workgroups; arrivals seen per XCD: %u %u %u %u %u %u %u %u of 32); unset IXTTS_MLP",
             m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8]);
   return IXTTS_ERR_STATE;
 }

@@ -220,10 +220,9 @@ __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, cons
   a.wt = wt; a.xin = xin; a.bias = bias; a.out = out; a.N = N; a.slot0 = slot0; a.out_stride = out_stride; a.smax = smax;
   a.kcache = kcache; a.vcache = vcache; a.cur_len = cur_len; a.heads = heads; a.nsplit = nsplit; a.ln_w = ln_w; a.ln_b = ln_b;
   a.norm_out = nullptr;
-  // EPI_QKV: `aux` = the per-XCD arrival counters of this layer's fused MLP kernel, cleared here (two kernel boundaries
-  // ahead of their use).  IN_LN_PART: ln_w = the partials [8][slots][K], ln_b = the bias to add, nsplit = slots, xout = the
+  // `aux` = the per-XCD arrival counters of this layer's fused MLP launch (two kernel boundaries ahead), cleared here.  IN_LN_PART: ln_w = the partials [8][slots][K], ln_b = the bias to add, nsplit = slots, xout = the
   // OTHER residual buffer, where the completed stream is published (in place would race with the workgroups still reading).
-  if (EPI == EPI_QKV && aux != nullptr && blockIdx.x == 0 && threadIdx.x < MLP_XCDS) aux[threadIdx.x * 32] = 0u;
+  if (aux != nullptr && blockIdx.x == 0 && threadIdx.x < MLP_XCDS) aux[threadIdx.x * 32] = 0u;
   TraceScope trace(EPI, IXTTS_TRACE_SEQ);
   constexpr int VEC = WVec<WT>::VEC;
   constexpr int PER = 64 * VEC;       // elements per wave-load
@@ -601,7 +600,7 @@ __global__ __launch_bounds__(64 * WPB) void gemv_lds_kernel(const void* wt, cons
 constexpr int MLP_D = 1280, MLP_FF = 5120, MLP_WAVES = 5, MLP_SLICE = MLP_FF / MLP_XCDS, MLP_ROWS_OUT = MLP_D / 32, MLP_KSUB = MLP_SLICE / MLP_WAVES;
 static_assert(MLP_SLICE == 640 && MLP_ROWS_OUT == 40 && MLP_KSUB == 128, "partition of the fused MLP");
 constexpr unsigned MLP_SPIN_MAX = 1u << 15;  // x ~0.4 us per poll: ~13 ms, three orders of magnitude above a healthy hand-off
-constexpr int MLP_CTR_STRIDE = MLP_XCDS * 32;  // uints per layer: one 128-byte line per XCD (the never-fused last layer's block holds the timeout mark)
+constexpr int MLP_CTR_STRIDE = MLP_XCDS * 32;  // uints per layer: one 128-byte line per XCD (the time-out mark follows the last layer's block)
 
 // sum over the 16 lanes of a DPP row; every lane of the row gets it (fixed order)
 __device__ __forceinline__ float group_sum16(float v) {
@@ -650,7 +649,7 @@ __global__ __launch_bounds__(64 * MLP_WAVES) void mlp_fused_kernel(const bf16* _
 #ifdef IXTTS_MLP_LOG
   const unsigned long long t_entry = wall_clock64();
   unsigned long long t_ff = 0, t_arrive = 0, t_rel = 0;
-  const bool logging = ctr == mark - (size_t)(gridDim.y + 12) * MLP_CTR_STRIDE;  // layer 10 of 24
+  const bool logging = ctr == mark - (size_t)(gridDim.y + 13) * MLP_CTR_STRIDE;  // layer 10 of 24
 #endif
   const int unit0 = ((xcd * 32 + j) * WPB + wave) * UNITS;  // ff rows 640 xcd + 20 j + 4 wave ...
 
