@@ -145,17 +145,6 @@ __global__ __launch_bounds__(AF_WAVES * 64) void attn_full_f32_kernel(AttnFullAr
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float mn = fmaxf(m_run, tmax);
     const float alpha = __builtin_amdgcn_exp2f(m_run - mn);  // 0 on the first tile (m = -inf)
-    float psum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(st[j][r] - mn);
-        st[j][r] = p;
-        psum += p;
-      }
-    psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * alpha + psum;
     m_run = mn;
     if (alpha != 1.0f) {  // (per lane; a stable running maximum leaves O^T untouched)
 #pragma unroll
@@ -163,6 +152,9 @@ __global__ __launch_bounds__(AF_WAVES * 64) void attn_full_f32_kernel(AttnFullAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[j][r] *= alpha;
     }
+    // the weights themselves are computed inside the PV loop below, each right before the MFMA step that consumes it, so
+    // that the 32 quarter-rate v_exp_f32 run under the matrix pipe instead of in front of it
+    float psum = 0.f;
     // ---- O^T += V^T P^T : k-step (j, r) pairs key (r&3)+8(r>>2) [lanes 0-31] with that key + 4 [lanes 32-63];
     //      the two A operands of a step are read one step ahead
     const float* vp = Vs + (4 * lh) * AF_D + l31;
@@ -178,10 +170,13 @@ __global__ __launch_bounds__(AF_WAVES * 64) void attn_full_f32_kernel(AttnFullAr
         va[(s + 1) & 1][0] = vrow[0];
         va[(s + 1) & 1][1] = vrow[32];
       }
-      const float pv = st[j][r];  // B[k = key][j = query]
+      const float pv = __builtin_amdgcn_exp2f(st[j][r] - mn);  // B[k = key][j = query]
+      psum += pv;
       ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s & 1][0], pv, ot[0], 0, 0, 0);
       ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s & 1][1], pv, ot[1], 0, 0, 0);
     }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
   }
   const int qi = q0 + l31;
   if (qi < a.T) {
