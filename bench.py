@@ -287,7 +287,7 @@ def main():
             traffic = None
         S_mid = P + n_codes // 2
         step_bytes = hp.gpt.step_bytes(B, S_mid)
-        step_us = stage_ms["gpt_gen"] / args.steps * 1e3 / n_codes  # includes prefill + host syncs
+        step_us = stage_ms["gpt_gen"] / args.steps * 1e3 / n_codes  # includes the conditioning encoders, both prefills and the host syncs (pessimistic by ~3 %)
         roofline = {
             "bound": "hbm", "kernel": f"gemv_reg_kernel<{args.dtype},K=1280,IN_LN,EPI_GELU> (decode LN2+FC, B={B})",
             "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
