@@ -431,3 +431,25 @@ def test_split_attention_across_context_buckets(golden, dev, monkeypatch, dtype)
         upto = int(close[0]) if close.size else 330
         assert upto > 315, upto  # both bucket boundaries (256 keys at step 55, 512 at step 311) are inside the compared range
         assert a0[:upto] == ref[:upto], [i for i, (x, y) in enumerate(zip(a0, ref)) if x != y][:3]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_rows_flash_attention_on_a_long_left_padded_prompt(golden, dev, dtype):
+    """Prefill of a 205-row prompt with 5 left-padding rows through the causal flash kernel (two 128-row workgroups, four
+    64-key tiles, `valid_from` = 5): last-row logits against the oracle's masked prefill."""
+    from voice_tts_amd.gpt_engine import GptEngine
+
+    g = golden("gpt_tiny.npz")
+    cfg, W, orc = _tiny(g)
+    gen = torch.Generator().manual_seed(5)
+    prompt = torch.cat([torch.zeros(5, cfg["model_dim"]), torch.randn(200, cfg["model_dim"], generator=gen) * 0.5])
+    mask = torch.cat([torch.zeros(5, dtype=torch.long), torch.ones(201, dtype=torch.long)])
+    ref, _ = orc.prefill(prompt, mask, 8192)
+    ref = ref.numpy()
+    eng = GptEngine(cfg, dtype=dtype, max_seq=512, max_batch=1, device=dev).load_state_dict(W)
+    eng.prefill(0, prompt, 5)
+    got = eng.read_logits(0)
+    tol = 3e-4 if dtype == "f32" else 5e-2
+    assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
+    if dtype == "f32":
+        assert int(got.argmax()) == int(ref.argmax())
