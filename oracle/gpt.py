@@ -267,6 +267,39 @@ def generate_greedy(oracle, embeds, mask, max_new, theta=10.0, stop_mel=8193, st
     return ids, margins
 
 
+def teacher_forced_logits(oracle, embeds, mask, ids, start_mel=8192):
+    """The decode loop's logits for a GIVEN id sequence in ONE causal pass (what `generate_greedy(forced=ids)` computes
+    step by step through the KV cache; tests/test_oracle_golden.py holds the two to each other): rows = the stored prompt
+    embeds, the start_mel row at mel position 0, then the k-th id (k >= 1) at mel position k + 1 (SURVEY F6,
+    model_v2.py:144-160); left padding through the key mask.  Returns logits [len(ids) + 1, V]: row k is the
+    distribution token k + 1 is chosen from (row 0 = the prefill logits)."""
+    W = oracle.W
+    ids = torch.as_tensor(ids, dtype=torch.long)
+    n = ids.numel()
+    rows = [torch.as_tensor(embeds, dtype=torch.float32), (W["mel_embedding.weight"][start_mel] + W["mel_pos_embedding.emb.weight"][0]).view(1, -1)]
+    if n:
+        rows.append(W["mel_embedding.weight"][ids] + W["mel_pos_embedding.emb.weight"][2: n + 2])
+    emb = torch.cat(rows, dim=0).unsqueeze(0)
+    P = len(mask)
+    km = torch.cat((torch.as_tensor(mask).view(1, -1), torch.ones(1, n, dtype=torch.long)), dim=1)
+    h, _ = oracle.trunk(emb, None, km)
+    return oracle.head(h[0, P - 1:])
+
+
+def greedy_choices(logits_rows, P, ids, theta=10.0, stop_mel=8193, start_mel=8192, suppress_stop=False):
+    """What `_sample` with top_k=1 picks at every step of a teacher-forced run: the argmax of the repetition-penalised row k
+    given the history [1]*(P-1)+[8192]+ids[:k] (F7), and its top-2 margin.  Returns (choices [n], margins [n])."""
+    hist = [1] * (P - 1) + [start_mel]
+    out, margins = [], []
+    for k in range(len(ids)):
+        s = process_logits(logits_rows[k], hist, theta, suppress=[stop_mel] if suppress_stop else None)
+        top2 = torch.topk(s, 2)
+        out.append(int(top2.indices[0]))
+        margins.append(float(top2.values[0] - top2.values[1]))
+        hist.append(int(ids[k]))
+    return out, margins
+
+
 # ------------------------------------------------------------------- beam-sample (G8, served default)
 class BeamHyps:
     """BeamHypotheses (indextts/gpt/transformers_beam_search.py:930-1013), length_penalty / early_stopping=False."""

@@ -309,13 +309,11 @@ def _load_folded_into_reference(module, W, prefix):
     return used
 
 
-def gen_s2mel():
-    import voice_tts_amd.s2mel as S2
+def build_ref_s2mel(cfg, W, max_T=64):
+    """The reference's MyModel (gpt_layer, length_regulator, CFM/DiT/WaveNet) + FactorizedVectorQuantize with our tensors."""
     from indextts.s2mel.modules.commons import MyModel
     from indextts.utils.maskgct.models.codec.amphion_codec.quantize.factorized_vector_quantize import FactorizedVectorQuantize
 
-    cfg = S2.tiny_s2mel_cfg(gpt_dim=1280, semantic_dim=1024, lr_in_channels=1024, codebook_size=8194)
-    W = S2.make_s2mel_weights(cfg, seed=71)
     args = _AD(
         reg_loss_type="l1", dit_type="DiT", style_encoder=_AD(dim=cfg["style_dim"]),
         length_regulator=_AD(channels=cfg["lr_channels"], is_discrete=False, in_channels=cfg["lr_in_channels"], content_codebook_size=2048,
@@ -329,7 +327,7 @@ def gen_s2mel():
                     dilation_rate=cfg["wavenet_dilation_rate"], p_dropout=0.2, style_condition=True),
     )
     m = MyModel(args, use_gpt_latent=True).eval()
-    m.models["cfm"].estimator.setup_caches(max_batch_size=2, max_seq_length=64)
+    m.models["cfm"].estimator.setup_caches(max_batch_size=2, max_seq_length=max(64, max_T))
     used = set()
     for key in ("cfm", "length_regulator", "gpt_layer"):
         used |= _load_folded_into_reference(m.models[key], W, key + ".")
@@ -337,9 +335,20 @@ def gen_s2mel():
     used |= _load_folded_into_reference(q, W, "quantizer.")
     missing = set(W) - used
     assert not missing, sorted(missing)[:5]
+    return m, q
 
-    g = torch.Generator().manual_seed(72)
-    n, Tp = 5, 7
+
+def gen_s2mel(name="s2mel_tiny.npz", seed=71, n=5, Tp=7, **cfg_kw):
+    """`s2mel_tiny.npz`: hidden 64 / 2 heads (head_dim 32).  `s2mel_hd64.npz`: hidden 128 / 2 heads -> head_dim 64, the
+    production head size, so the GPU test of this fixture runs through `attn_full_f32_kernel` (s2mel.py `_attention`), and
+    long enough (T = 70 + 154) to cross the kernel's 32-query / 64-key tile edges."""
+    import voice_tts_amd.s2mel as S2
+
+    cfg = S2.tiny_s2mel_cfg(gpt_dim=1280, semantic_dim=1024, lr_in_channels=1024, codebook_size=8194, **cfg_kw)
+    W = S2.make_s2mel_weights(cfg, seed=seed)
+    m, q = build_ref_s2mel(cfg, W, Tp + int(n * 1.72))
+
+    g = torch.Generator().manual_seed(seed + 1)
     latent = torch.randn(1, n, 1280, generator=g) * 0.5
     codes = torch.randint(0, 8192, (1, n), generator=g)
     code_lens = torch.tensor([n])
@@ -359,8 +368,63 @@ def gen_s2mel():
     with torch.inference_mode():
         mel = cfm.solve_euler(noise.clone(), torch.LongTensor([T]), ref_mel, cat_condition.clone(), style, None, t_span, inference_cfg_rate=0.7)
         one = cfm.estimator(noise, torch.zeros_like(noise), torch.LongTensor([T]), torch.tensor([0.3]), style, cat_condition)
-    save("s2mel_tiny.npz", seed=71, latent=latent, codes=codes, prompt_condition=prompt_condition, ref_mel=ref_mel, style=style,
+    save(name, seed=seed, latent=latent, codes=codes, prompt_condition=prompt_condition, ref_mel=ref_mel, style=style,
          noise=noise, gpt_layer_out=lat, vq_emb=q.vq2emb(codes).transpose(1, 2), cond=cond, dit_one=one, mel=mel[:, :, Tp:], n_steps=3)
+
+
+# ----------------------------------------------------------------------------- chain (SURVEY 8(d) config 1 on twins)
+def gen_chain():
+    """The reference's own segment chain on small twins (infer_v2.py:641-744): UnifiedVoice greedy decode (harness loop,
+    SURVEY F5) -> UnifiedVoice.forward latent -> MyModel gpt_layer + vq2emb + length_regulator + CFM (noise injected,
+    SURVEY F9) -> BigVGAN -> clamp(32767 x) -> int16.  Every stage output is stored, so a chained implementation is held to
+    the END of the chain (waveform / PCM) with its own intermediate values, not stage by stage on fresh inputs."""
+    import voice_tts_amd.s2mel as S2
+
+    # MyModel.gpt_layer is fixed 1280 -> 256 -> 128 -> 1024 (commons.py:420-424): the GPT twin keeps the production width
+    gcfg = WR.tiny_gpt_cfg(model_dim=1280, layers=2, heads=20)
+    Wg = WR.make_gpt_weights(gcfg, seed=91, head_scale=50.0)
+    uv = build_ref_gpt(gcfg, Wg)
+    scfg = S2.tiny_s2mel_cfg(gpt_dim=1280, semantic_dim=1024, lr_in_channels=1024, codebook_size=8194, hidden_dim=128, num_heads=2,
+                             wavenet_hidden=128, depth=3)  # head_dim 64: the HIP attention kernel is on the chain
+    Ws = S2.make_s2mel_weights(scfg, seed=92)
+    bcfg = WR.tiny_bigvgan_cfg(64)
+    Wb = WR.make_bigvgan_weights(bcfg, seed=93)
+    g = torch.Generator().manual_seed(94)
+    D = gcfg["model_dim"]
+    cond32 = torch.randn(32, D, generator=g) * 0.5
+    emo_vec = torch.randn(D, generator=g) * 0.5
+    conds_latent = torch.cat((cond32 + emo_vec.unsqueeze(0), uv.speed_emb.weight[1:2], uv.speed_emb.weight[0:1]), 0)
+    text = torch.randint(2, 200, (14,), generator=g).to(torch.int32)
+    n, Tp = 48, 30
+    ids, margins, _, _, _ = ref_greedy(uv, conds_latent, text, n)
+    assert 8193 not in ids
+    codes = torch.tensor(ids).unsqueeze(0)
+    t = text.long().unsqueeze(0)
+    latent = uv(cond32.unsqueeze(0), t.clone(), torch.tensor([t.shape[-1]]), codes.clone(), torch.tensor([n]), None,
+                emo_vec=emo_vec.unsqueeze(0), use_speed=torch.zeros(1).long())
+    T = Tp + int(n * 1.72)
+    m, q = build_ref_s2mel(scfg, Ws, T)
+    prompt_condition = torch.randn(1, Tp, scfg["content_dim"], generator=g)
+    ref_mel = (torch.randn(1, 80, Tp, generator=g) * 2 - 4).clamp(-11.5, 2)
+    style = torch.randn(1, scfg["style_dim"], generator=g)
+    noise = torch.randn(1, 80, T, generator=g)
+    # infer_v2.py:713-731
+    lat = m.models["gpt_layer"](latent)
+    S_infer = q.vq2emb(codes).transpose(1, 2) + lat
+    cond = m.models["length_regulator"](S_infer, ylens=(torch.tensor([n]) * 1.72).long(), n_quantizers=3, f0=None)[0]
+    cat_condition = torch.cat([prompt_condition, cond], dim=1)
+    n_steps = 4
+    with torch.inference_mode():
+        mel = m.models["cfm"].solve_euler(noise.clone(), torch.LongTensor([T]), ref_mel, cat_condition.clone(), style, None,
+                                          torch.linspace(0, 1, n_steps + 1), inference_cfg_rate=0.7)[:, :, Tp:]
+    voc = build_ref_bigvgan(bcfg, Wb)
+    wav = voc(mel.float()).squeeze().unsqueeze(0)  # infer_v2.py:735-736
+    wav = torch.clamp(32767 * wav, -32767.0, 32767.0)  # :740
+    pcm = wav.type(torch.int16)  # :781
+    print("chain: ids", ids[:10], "min margin", min(margins), "mel range", float(mel.min()), float(mel.max()), "wav max", float(wav.abs().max()))
+    save("chain_tiny.npz", seeds=np.array([91, 92, 93]), cond32=cond32, emo_vec=emo_vec, conds_latent=conds_latent, text=text, ids=np.array(ids),
+         margins=np.array(margins), latent=latent[0], prompt_condition=prompt_condition, ref_mel=ref_mel, style=style, noise=noise, n_steps=n_steps,
+         mel=mel, wav=wav, pcm=pcm)
 
 
 # ----------------------------------------------------------------------------- N2 (conditioning encoders)
@@ -536,8 +600,28 @@ def gen_front():
           "split errors", sum("error" in r for r in out["split"]), "warned", sum(r["warned"] for r in out["split"]))
 
 
+def gen_emotion():
+    """The /tts emotion-label vocabulary and known answers of the reference's emotion.py (imports as-is)."""
+    import json
+
+    import emotion as RE  # /root/reference/emotion.py
+
+    probes = ["happy", " Joyful ", "ANXIOUS", "紧张", "normal", "glad", "rage", "no-such-label", "", "惊喜", "stunned"]
+    dicts = [{"高兴": 0.7, "平静": 0.3}, {"happy": 0.7, "joyful": 0.5}, {"开心": 0.8, "生气": 0.2}, {"anxious": 0.4, "panic": 0.9, "??": 0.6},
+             {"downcast": 1.0, "低沉": 0.2, "calmness": 0.1}, {}]
+    out = {"order": RE.STANDARD_EMOTION_ORDER, "mapping": RE.EMOTION_MAPPING,
+           "label_cases": [{"label": p, "standard": RE.normalize_emotion_label(p)} for p in probes],
+           "string_cases": [{"label": p, "alpha": a, "vector": RE.create_emotion_vector(p, a)} for p in probes for a in (1.0, 0.35)],
+           "dict_cases": [{"input": d, "vector": RE.create_emotion_vector(d)} for d in dicts]}
+    with open(os.path.join(HERE, "emotion_labels.json"), "w", encoding="utf-8") as f:
+        json.dump(out, f, ensure_ascii=False, indent=0)
+    print("emotion_labels.json:", len(out["mapping"]), "labels")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["aa", "bigvgan", "gpt", "prod", "sampler", "beam", "s2mel", "cond", "front"]
+    which = sys.argv[1:] or ["emotion", "aa", "bigvgan", "gpt", "prod", "sampler", "beam", "s2mel", "chain", "cond", "front"]
+    if "emotion" in which:
+        gen_emotion()
     if "aa" in which:
         gen_aa_snake()
     if "bigvgan" in which:
@@ -552,6 +636,9 @@ if __name__ == "__main__":
         gen_beam()
     if "s2mel" in which:
         gen_s2mel()
+        gen_s2mel("s2mel_hd64.npz", seed=73, n=90, Tp=70, hidden_dim=128, num_heads=2, wavenet_hidden=128, depth=3)
+    if "chain" in which:
+        gen_chain()
     if "cond" in which:
         gen_conditioning()
     if "front" in which:

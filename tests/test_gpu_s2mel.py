@@ -10,13 +10,20 @@ def dev():
     return torch.device("cuda:0")
 
 
-def test_s2mel_on_gpu_vs_reference_fixture(golden):
+@pytest.mark.parametrize("fx,kw", [("s2mel_tiny.npz", {}), ("s2mel_hd64.npz", dict(hidden_dim=128, num_heads=2, wavenet_hidden=128, depth=3))])
+def test_s2mel_on_gpu_vs_reference_fixture(golden, fx, kw, monkeypatch):
+    """`s2mel_hd64.npz` is the reference's MyModel / CFM / DiT at head_dim 64: its attention runs through
+    `attn_full_f32_kernel` + `ixtts_rope_qk_f32` (asserted by counting the calls), so the HIP attention is held to
+    reference output, not only to torch SDPA."""
     import voice_tts_amd.s2mel as S2
 
-    g = golden("s2mel_tiny.npz")
+    g = golden(fx)
     dev = torch.device("cuda:0")
-    cfg = S2.tiny_s2mel_cfg(gpt_dim=1280, semantic_dim=1024, lr_in_channels=1024, codebook_size=8194)
+    cfg = S2.tiny_s2mel_cfg(gpt_dim=1280, semantic_dim=1024, lr_in_channels=1024, codebook_size=8194, **kw)
     m = S2.S2Mel(S2.make_s2mel_weights(cfg, seed=int(g["seed"])), cfg, device=dev)
+    calls = []
+    real = S2.attn_full
+    monkeypatch.setattr(S2, "attn_full", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     t = lambda k: torch.from_numpy(g[k]).to(dev)
     n = g["codes"].shape[1]
     mel = m(t("latent"), t("codes"), torch.tensor([n], device=dev), t("prompt_condition"), t("ref_mel"), t("style"),
@@ -24,6 +31,8 @@ def test_s2mel_on_gpu_vs_reference_fixture(golden):
     ref = torch.from_numpy(g["mel"])
     assert mel.shape == ref.shape
     assert (mel - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    hd = cfg["hidden_dim"] // cfg["num_heads"]
+    assert (len(calls) == int(g["n_steps"]) * cfg["depth"]) if hd == 64 else not calls, (hd, len(calls))
 
 
 @pytest.mark.parametrize("B,H,T", [(2, 8, 2322), (1, 3, 301), (1, 1, 64), (2, 2, 65), (1, 2, 1)])

@@ -93,6 +93,14 @@ def test_gpt_prompt_and_greedy_vs_reference(golden, tag):
     ref_logits = torch.from_numpy(g[f"logits_{tag}"])
     got = logits[[0, 1, 2, n - 1]]
     assert (got - ref_logits).abs().max().item() <= 5e-4 * ref_logits.abs().max().item()
+    # the one-pass teacher-forced form (what the full-size GPU tests check the device against) == the cached step loop,
+    # and through it the reference's own forward: same logits at every step, same greedy choices (left padding included)
+    one = OG.teacher_forced_logits(orc, embeds, mask, ref_ids)
+    assert one.shape == (n + 1, logits.shape[1])
+    assert (one[:n] - logits).abs().max().item() <= 2e-4 * logits.abs().max().item()
+    assert (one[[0, 1, 2, n - 1]] - ref_logits).abs().max().item() <= 5e-4 * ref_logits.abs().max().item()
+    picks, m2 = OG.greedy_choices(one, len(mask), ref_ids)
+    assert picks == ref_ids and np.allclose(m2, g[f"margins_{tag}"], atol=2e-3)
 
 
 def test_gpt_latent_pass_vs_reference(golden):

@@ -8,8 +8,11 @@ import torch
 import voice_tts_amd.s2mel as S2
 
 
-def _model(g, device="cpu"):
-    cfg = S2.tiny_s2mel_cfg(gpt_dim=1280, semantic_dim=1024, lr_in_channels=1024, codebook_size=8194)
+FIXTURES = {"s2mel_tiny.npz": {}, "s2mel_hd64.npz": dict(hidden_dim=128, num_heads=2, wavenet_hidden=128, depth=3)}
+
+
+def _model(g, device="cpu", **kw):
+    cfg = S2.tiny_s2mel_cfg(gpt_dim=1280, semantic_dim=1024, lr_in_channels=1024, codebook_size=8194, **kw)
     W = S2.make_s2mel_weights(cfg, seed=int(g["seed"]))
     return S2.S2Mel(W, cfg, device=device), cfg
 
@@ -18,9 +21,10 @@ def _t(g, k, device="cpu"):
     return torch.from_numpy(g[k]).to(device)
 
 
-def test_s2mel_stages_vs_reference(golden):
-    g = golden("s2mel_tiny.npz")
-    m, cfg = _model(g)
+@pytest.mark.parametrize("fx", list(FIXTURES))
+def test_s2mel_stages_vs_reference(golden, fx):
+    g = golden(fx)
+    m, cfg = _model(g, **FIXTURES[fx])
     lat = m.gpt_layer(_t(g, "latent"))
     assert torch.allclose(lat, _t(g, "gpt_layer_out"), atol=2e-5)
     emb = m.vq2emb(_t(g, "codes"))
@@ -36,9 +40,10 @@ def test_s2mel_stages_vs_reference(golden):
     assert (one - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
-def test_s2mel_end_to_end_vs_reference(golden):
-    g = golden("s2mel_tiny.npz")
-    m, cfg = _model(g)
+@pytest.mark.parametrize("fx", list(FIXTURES))
+def test_s2mel_end_to_end_vs_reference(golden, fx):
+    g = golden(fx)
+    m, cfg = _model(g, **FIXTURES[fx])
     n = g["codes"].shape[1]
     mel = m(_t(g, "latent"), _t(g, "codes"), torch.tensor([n]), _t(g, "prompt_condition"), _t(g, "ref_mel"), _t(g, "style"),
             n_timesteps=int(g["n_steps"]), inference_cfg_rate=0.7, noise=_t(g, "noise"))

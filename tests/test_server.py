@@ -111,3 +111,20 @@ def test_emotion_known_answers_and_helpers():
     assert is_hex_string("ab" * 51) and not is_hex_string("ab" * 50) and not is_hex_string("zz" * 60) and not is_hex_string("abc" * 41)
     # gunicorn worker -> GPU, round robin over the visible list (gunicorn_config.py:53-54)
     assert [worker_gpu(a, "0,1,2") for a in (1, 2, 3, 4)] == ["0", "1", "2", "0"] and worker_gpu(1, "") is None
+
+
+def test_emotion_vocabulary_equals_the_reference_for_every_label():
+    """tests/golden/emotion_labels.json = the reference's EMOTION_MAPPING and create_emotion_vector answers (make_golden.py
+    `gen_emotion`): the label -> dimension table is wire behaviour, so all 119 keys must agree and nothing else be accepted."""
+    import json
+    import os
+
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "emotion_labels.json"), encoding="utf-8"))
+    assert EM.STANDARD_EMOTION_ORDER == g["order"]
+    assert EM.EMOTION_MAPPING == g["mapping"] and len(g["mapping"]) == 119
+    for c in g["label_cases"]:
+        assert EM.normalize_emotion_label(c["label"]) == c["standard"], c
+    for c in g["string_cases"]:
+        assert EM.create_emotion_vector(c["label"], c["alpha"]) == c["vector"], c
+    for c in g["dict_cases"]:
+        assert EM.create_emotion_vector(c["input"]) == c["vector"], c

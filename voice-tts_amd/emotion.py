@@ -1,10 +1,11 @@
 """Emotion labels -> the 8-dimensional emotion vector `IndexTTS2.infer(emo_vector=...)` takes.
 
-Mirrors the behaviour of the reference's `emotion.py` (`create_emotion_vector`, :279-327; order of the dimensions :27;
-unknown labels fall back to "calm", :206-212; a dimension named twice keeps the larger value, :238-243).  The synonym
-table below is this repository's own (the eight canonical names in both languages as the `/tts` request documents them,
-`server.py:189-199`, plus everyday synonyms); the reference's docstring examples (:269-273, :300-304) are the known
-answers `tests/test_server.py` checks.
+Mirrors the reference's `emotion.py`: `create_emotion_vector` (:257-290), the order of the dimensions (:27), unknown
+labels fall back to "calm" with a warning (:206-212), a dimension named twice keeps the larger value (:238-243).  The
+label vocabulary is part of the `/tts` wire contract (which of the 8 dimensions a request's `emotion` string drives), so the
+table below holds exactly the reference's 119 labels (`EMOTION_MAPPING`, :31-187) -- no more, no fewer;
+`tests/golden/emotion_labels.json` (written from the imported reference module by tests/golden/make_golden.py) freezes every
+label and `tests/test_server.py` checks all of them.
 """
 import logging
 
@@ -12,25 +13,17 @@ logger = logging.getLogger("indextts.emotion")
 
 STANDARD_EMOTION_ORDER = ["happy", "angry", "sad", "afraid", "disgusted", "melancholic", "surprised", "calm"]
 
-_SYNONYMS = {
-    "happy": ("happy happiness joy joyful cheerful delighted pleased excited glad "
-              "高兴 快乐 开心 愉快 欢乐 喜悦 兴奋 欣喜"),
-    "angry": ("angry anger mad furious irritated annoyed enraged rage "
-              "愤怒 生气 发怒 恼怒 气愤 暴怒 恼火"),
-    "sad": ("sad sadness sorrow sorrowful unhappy grief upset "
-            "悲伤 难过 忧伤 伤心 悲痛 哀伤 悲哀"),
-    "afraid": ("afraid fear fearful scared frightened terrified panic "
-               "恐惧 害怕 恐慌 惊恐 畏惧 惧怕"),
-    "disgusted": ("disgusted disgust disgusting revolted repulsed "
-                  "反感 厌恶 恶心 嫌弃 讨厌 憎恶"),
-    "melancholic": ("melancholic melancholy depressed gloomy down dejected low "
-                    "低落 忧郁 沮丧 消沉 郁闷 抑郁"),
-    "surprised": ("surprised surprise astonished amazed shocked startled "
-                  "惊讶 吃惊 震惊 惊奇 诧异 惊喜"),
-    "calm": ("calm neutral peaceful relaxed natural serene "
-             "平静 自然 淡定 平和 安静 宁静 放松 冷静 中性"),
+_LABELS = {
+    "happy": "happy happiness joy joyful cheerful delighted pleased excited 高兴 快乐 开心 愉快 欢乐 喜悦 兴奋 欣喜",
+    "angry": "angry anger mad furious irritated annoyed enraged 愤怒 生气 发怒 恼怒 气愤 火大",
+    "sad": "sad sadness unhappy sorrow sorrowful grief heartbroken 悲伤 难过 伤心 忧伤 哀伤 痛苦 悲痛",
+    "afraid": "afraid fear fearful scared frightened terrified anxious nervous panic panicked 恐惧 害怕 恐慌 惊恐 畏惧 紧张",
+    "disgusted": "disgusted disgust disgusting repulsed revolted nauseated 反感 厌恶 恶心 讨厌 反胃 嫌弃",
+    "melancholic": "melancholic melancholy depressed depression gloomy downcast dejected despondent 低落 忧郁 沮丧 消沉 抑郁 颓废 低沉",
+    "surprised": "surprised surprise astonished amazed shocked startled stunned 惊讶 吃惊 震惊 惊奇 诧异 惊诧 愕然",
+    "calm": "calm normal calmness peaceful serene tranquil relaxed composed neutral natural 平静 自然 淡定 平和 安静 宁静 放松 冷静 中性",
 }
-EMOTION_MAPPING = {w: std for std, words in _SYNONYMS.items() for w in words.split()}
+EMOTION_MAPPING = {w: std for std, words in _LABELS.items() for w in words.split()}
 
 
 def normalize_emotion_label(label):
