@@ -427,6 +427,42 @@ def gen_chain():
          mel=mel, wav=wav, pcm=pcm)
 
 
+# ----------------------------------------------------------------------------- prompt-side glue (infer_v2.py:508-580)
+def gen_prompt():
+    """Reference classes of the once-per-prompt stages with our seeded tensors loaded: CAMPPlus (campplus/DTDNN.py), RepCodec.quantize
+    (repcodec_model.py:176-196) and s2mel/modules/audio.py `mel_spectrogram`.  librosa is absent, so the mel BASIS handed to the
+    reference function is ours (`slaney_mel_basis`): the fixture pins the padding / STFT / magnitude / log part, not the basis."""
+    import voice_tts_amd.prompt as PR
+    from indextts.s2mel.modules import audio as RA
+    from indextts.s2mel.modules.campplus.DTDNN import CAMPPlus
+    from indextts.utils.maskgct.models.codec.kmeans.repcodec_model import RepCodec
+
+    g = torch.Generator().manual_seed(101)
+    out = {}
+    Wc = PR.make_camplus_weights(seed=102)
+    cam = CAMPPlus(feat_dim=80, embedding_size=192).eval()
+    sd = cam.state_dict()
+    assert set(Wc) == {k for k in sd if not k.endswith("num_batches_tracked")}
+    cam.load_state_dict({k: Wc.get(k, v) for k, v in sd.items()}, strict=True)
+    for T in (215, 57):
+        feat = torch.randn(1, T, 80, generator=g) * 2.0
+        feat = feat - feat.mean(dim=1, keepdim=True)
+        out[f"cam_feat_{T}"] = feat
+        out[f"cam_style_{T}"] = cam(feat)
+    ccfg = dict(codebook_size=50, hidden_size=48, codebook_dim=8, vocos_dim=32, vocos_intermediate_dim=64, vocos_num_layers=3)
+    Wq = PR.make_codec_weights(ccfg, seed=103)
+    codec = RepCodec(**ccfg).eval()
+    used = _load_folded_into_reference(codec, Wq, "")
+    assert not (set(Wq) - used), sorted(set(Wq) - used)[:5]
+    x = torch.randn(2, 33, 48, generator=g)
+    codes, S_ref = codec.quantize(x)
+    out.update(codec_x=x, codec_codes=codes, codec_S=S_ref, codec_cfg=np.array(list(ccfg.values())))
+    RA.librosa_mel_fn = lambda sr, n_fft, n_mels, fmin, fmax: PR.slaney_mel_basis(sr, n_fft, n_mels, fmin, fmax)
+    y = torch.randn(1, 22050, generator=g) * 0.1
+    out.update(mel_y=y, mel_out=RA.mel_spectrogram(y, n_fft=1024, num_mels=80, sampling_rate=22050, hop_size=256, win_size=1024, fmin=0, fmax=None, center=False))
+    save("prompt_tiny.npz", seeds=np.array([102, 103]), **out)
+
+
 # ----------------------------------------------------------------------------- N2 (conditioning encoders)
 def gen_conditioning():
     """Reference ConformerEncoder + PerceiverResampler composed exactly as UnifiedVoice.get_conditioning / get_emovec /
@@ -619,7 +655,7 @@ def gen_emotion():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["emotion", "aa", "bigvgan", "gpt", "prod", "sampler", "beam", "s2mel", "chain", "cond", "front"]
+    which = sys.argv[1:] or ["emotion", "aa", "bigvgan", "gpt", "prod", "sampler", "beam", "s2mel", "chain", "prompt", "cond", "front"]
     if "emotion" in which:
         gen_emotion()
     if "aa" in which:
@@ -639,6 +675,8 @@ if __name__ == "__main__":
         gen_s2mel("s2mel_hd64.npz", seed=73, n=90, Tp=70, hidden_dim=128, num_heads=2, wavenet_hidden=128, depth=3)
     if "chain" in which:
         gen_chain()
+    if "prompt" in which:
+        gen_prompt()
     if "cond" in which:
         gen_conditioning()
     if "front" in which:

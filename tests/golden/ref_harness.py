@@ -62,6 +62,9 @@ def install():
         except Exception:
             ta = _mod("torchaudio", load=None)
             ta.functional = _mod("torchaudio.functional")
+            ta.functional.__path__ = []
+            # kmeans/vocos.py:14 imports two mel helpers for feature classes the codec path never builds
+            ta.functional.functional = _mod("torchaudio.functional.functional", _hz_to_mel=None, _mel_to_hz=None)
             ta.transforms = _mod("torchaudio.transforms")
             ta.compliance = _mod("torchaudio.compliance")
             ta.compliance.kaldi = _mod("torchaudio.compliance.kaldi")

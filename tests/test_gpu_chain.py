@@ -37,6 +37,6 @@ def test_hip_chain_vs_reference_chain(golden):
     ref = torch.from_numpy(g["wav"])
     e_wav = (scaled - ref).abs().max().item() / 32767
     print(f"chain: latent err {e_lat:.2e}, mel err {e_mel:.2e}, waveform err {e_wav:.2e} (fp32 full scale 1.0)")
-    assert e_lat <= 1e-4 and e_mel <= 2e-4 * max(1.0, float(np.abs(g["mel"]).max())) and e_wav <= 1e-3
+    assert e_lat <= 1e-4 and e_mel <= 2e-4 * max(1.0, float(np.abs(g["mel"]).max())) and e_wav <= 1e-4  # north_star asks 1e-3; measured 1.3e-6
     bad, worst, covered = pcm_mismatch(scaled, g["pcm"], g["wav"])
     assert bad == 0 and worst <= 1 and covered > 0.5, (bad, worst, covered)

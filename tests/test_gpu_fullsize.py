@@ -55,7 +55,8 @@ def test_gpt_24_layers_fp32_greedy_bit_exact(gpt_full, dev):
 
 
 def test_gpt_24_layers_bf16_token_agreement(gpt_full, dev):
-    """Throughput mode at full depth: reports agreement with the fp32 oracle (not required to be exact)."""
+    """Throughput mode at full depth, config-1 shape: first logits within 2e-2 of the fp32 oracle's, >= 21 of 24 free-running
+    greedy tokens equal (the 1100-step bound is test_bench_shape_bf16_1100_steps_vs_oracle)."""
     import voice_tts_amd.weights as WR
     from voice_tts_amd.gpt_engine import GptEngine
 
@@ -64,12 +65,12 @@ def test_gpt_24_layers_bf16_token_agreement(gpt_full, dev):
     eng.prefill(0, embeds, 0)
     l0 = eng.read_logits(0)
     rel = np.abs(l0 - logits[0].numpy()).max() / np.abs(logits[0].numpy()).max()
-    assert rel <= 5e-2, rel
+    assert rel <= 2e-2, rel
     eng.decode(1, len(ids), repetition_penalty=10.0, suppress_stop=True)
     out, _ = eng.read(0)
     agree = int(np.sum(np.array(out.tolist()) == np.array(ids)))
     print(f"bf16 vs fp32-oracle: first-logit rel err {rel:.2e}, token agreement {agree}/{len(ids)}")
-    assert out.tolist()[0] == ids[0] or margins[0] < 0.05 * float(logits.abs().max())
+    assert agree >= 21, (agree, out.tolist(), ids)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -134,7 +135,7 @@ def _oracle_rows(orc, prompts, ids):
 
 def test_bench_shape_fp32_1100_steps_vs_oracle(gpt_full, bench_prompts, dev):
     """Parity mode at the benchmarked shape: every one of the 2 x 1100 device tokens is the oracle's greedy choice given the
-    same history (exact wherever the oracle's own top-2 margin exceeds fp32 reduction noise), and the logits read at 30+
+    same history (exact wherever the oracle's own top-2 margin exceeds 1e-4 of the logit scale), and the logits read at 30+
     steps -- including both sides of every 256-key bucket switch -- are within 3e-4 of the logit scale."""
     W, orc = gpt_full[0], gpt_full[1]
     ids, got = _run_bench_shape(W, bench_prompts, "f32", dev)
@@ -143,18 +144,21 @@ def test_bench_shape_fp32_1100_steps_vs_oracle(gpt_full, bench_prompts, dev):
         rows, picks, margins = ref[b]
         scale = float(rows.abs().max())
         worst = max(np.abs(got[k][b] - rows[k].numpy()).max() for k in got) / scale
-        close = [k for k in range(N_BENCH) if margins[k] < 1e-3 * scale]
-        wrong = [k for k in range(N_BENCH) if picks[k] != int(ids[b][k]) and margins[k] >= 1e-3 * scale]
-        print(f"fp32 slot {b}: logits rel err {worst:.2e} over {len(got)} read points, {len(close)} near-tie steps, {len(wrong)} wrong tokens")
+        # "near tie" = the oracle's own top-2 margin below 1e-4 of the logit scale (the measured logit error is ~2e-6 of it)
+        close = [k for k in range(N_BENCH) if margins[k] < 1e-4 * scale]
+        differ = [k for k in range(N_BENCH) if picks[k] != int(ids[b][k])]
+        wrong = [k for k in differ if margins[k] >= 1e-4 * scale]
+        print(f"fp32 slot {b}: logits rel err {worst:.2e} over {len(got)} read points, {len(close)} near-tie steps, "
+              f"{len(differ)} differing tokens, {len(wrong)} of them outside near-ties")
         assert worst <= 3e-4, (b, worst)
         assert not wrong, (b, wrong[:5])
-        assert len(close) <= 5  # the synthetic head keeps margins wide: near-ties must stay the exception
+        assert len(close) <= 10 and len(differ) <= len(close)
 
 
 def test_bench_shape_bf16_1100_steps_vs_oracle(gpt_full, bench_prompts, dev):
     """The benchmarked mode (bf16 weights + KV, fp32 accumulate) against the fp32 CPU oracle, teacher-forced on the device's own
-    ids: stated bounds -- logits within 3e-2 of the logit scale at every read point, and the device token equals the fp32
-    oracle's greedy choice at >= 97 % of the 2 x 1100 steps."""
+    ids: stated bounds -- logits within 1.5e-2 of the logit scale at every read point (measured 5.6e-3), and the device token
+    equals the fp32 oracle's greedy choice at >= 95 % of the 2 x 1100 steps (measured 97.8 % / 98.5 %)."""
     W, orc = gpt_full[0], gpt_full[1]
     ids, got = _run_bench_shape(W, bench_prompts, "bf16", dev)
     ref = _oracle_rows(orc, bench_prompts, ids)
@@ -166,13 +170,13 @@ def test_bench_shape_bf16_1100_steps_vs_oracle(gpt_full, bench_prompts, dev):
         top1 = sum(int(np.argmax(got[k][b]) == int(rows[k].argmax())) for k in got) / len(got)
         print(f"bf16 slot {b}: logits rel err max {max(errs.values()):.2e} (step {max(errs, key=errs.get)}), greedy agreement {agree:.4f}, "
               f"raw top-1 agreement at read points {top1:.3f}")
-        assert max(errs.values()) <= 3e-2, (b, errs)
-        assert agree >= 0.97, (b, agree)
+        assert max(errs.values()) <= 1.5e-2, (b, errs)
+        assert agree >= 0.95, (b, agree)
 
 
 def test_bigvgan_full_size_config5_mel(dev):
     """BASELINE configs[4]: the 1000-frame microbench mel through the production generator vs the CPU oracle, <= 1e-3
-    (north_star) -- asserted at 3e-4."""
+    (north_star) -- asserted at 5e-5 (measured 6e-6)."""
     from oracle import vocoder as OV
     import voice_tts_amd.weights as WR
     from voice_tts_amd.bigvgan import BigVGAN
@@ -186,7 +190,7 @@ def test_bigvgan_full_size_config5_mel(dev):
     assert wav.shape == ref.shape == (1, 1, 256000)
     err = (wav - ref).abs().max().item()
     print(f"BigVGAN F=1000: max|err| {err:.2e}, ref max {ref.abs().max().item():.3f}")
-    assert ref.abs().max() > 0.05 and err <= 3e-4, err
+    assert ref.abs().max() > 0.05 and err <= 5e-5, err
 
 
 @pytest.mark.parametrize("B", [1, 2, 3])

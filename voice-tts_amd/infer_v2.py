@@ -2,15 +2,18 @@
 
 Same constructor and `infer(...)` signature, return values, wav format and log lines as the
 reference (`indextts/infer_v2.py:36-45,438-461,463-783`).  The two hot stages -- the GPT
-(`inference_speech` + latent `forward`) and BigVGAN -- run in libixtts_hip.so.  Of the stages
-`north_star` leaves to PyTorch glue this repository builds the conformer/perceiver conditioners
-(`conditioning.py`, used when the GPT checkpoint carries their weights) and the s2mel
-length-regulator + CFM (`s2mel.py`, used when `s2mel_state_dict` is given); audio loading,
-w2v-bert features, the semantic codec, CAM++ and the text front-end are NOT implemented: they are
-supplied through a `glue` object (see `Glue`), and `infer()` raises a clear `NotImplementedError`
-when it is missing.  That keeps the orchestration (segment loop, generation kwargs, stop-token
-trimming, PCM conversion, silence insertion, streaming) testable today and lets the reference's
-own modules be plugged in unchanged where they are available.
+(`inference_speech` + latent `forward`) and BigVGAN -- run in libixtts_hip.so; the stages
+`north_star` leaves to PyTorch glue run on the same device through this package's torch
+restatements: conformer/perceiver conditioners (`conditioning.py`), s2mel length regulator + CFM
+(`s2mel.py`), and the once-per-prompt stages of infer_v2.py:508-580 (`prompt.py`: audio decode of
+the five prompt forms, resampling, w2v-bert features through the installed `transformers`
+classes, semantic codec `quantize`, reference mel, kaldi fbank + CAM++, emotion-matrix mix).
+
+`IndexTTS2(cfg_path, model_dir).infer(wav, text)` therefore runs from the files of `model_dir`
+alone (layout in INTEGRATION.md; nothing is ever downloaded); every component can also be handed
+in as tensors (`*_state_dict=`, `w2v_bert=`, `emo_matrix=` ...), which is how the tests and the
+bench build synthetic twins.  A `glue=` object still overrides any stage (see `Glue`).  There is
+no silent fallback: a stage whose weights are missing makes `infer()` raise, naming the file.
 """
 import logging
 import os
@@ -23,13 +26,71 @@ import torch
 
 from .bigvgan import BigVGAN
 from .gpt_engine import GptEngine
+from .pipeline import prepare_gpt_inputs
 from .weights import BIGVGAN_CFG, GPT_CFG, load_bigvgan_checkpoint, load_gpt_checkpoint
 
 logger = logging.getLogger("indextts.infer_v2")
 
 
+def _same_prompt(a, b):
+    """The reference's cache test `cache_spk_audio_prompt != spk_audio_prompt` (infer_v2.py:508,566) for every prompt form:
+    equal paths / bytes hit the cache even when they are distinct objects; arrays and tensors compare by content."""
+    if a is b:
+        return True
+    if type(a) is not type(b):
+        return False
+    if isinstance(a, tuple):
+        return len(a) == len(b) and all(_same_prompt(x, y) for x, y in zip(a, b))
+    if isinstance(a, np.ndarray):
+        return a.shape == b.shape and bool(np.array_equal(a, b))
+    if isinstance(a, torch.Tensor):
+        return a.shape == b.shape and bool(torch.equal(a, b))
+    try:
+        return bool(a == b)
+    except Exception:
+        return False
+
+
+def load_s2mel_checkpoint(path):
+    """`load_checkpoint2` (s2mel/modules/commons.py:568-624): {"net": {module: state_dict}}, DDP "module." prefixes stripped;
+    flattened to `module.key` as `S2Mel` reads them.  Tensors only (weights_only)."""
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    net = sd["net"] if "net" in sd else sd
+    out = {}
+    for mod, params in net.items():
+        if not isinstance(params, dict):
+            continue
+        for k, v in params.items():
+            k = k[7:] if k.startswith("module.") else k
+            if torch.is_tensor(v) and v.is_floating_point():
+                out[f"{mod}.{k}"] = v.float()
+    return out
+
+
+def _s2mel_cfg_from_yaml(y, base):
+    """`cfg.s2mel` (Appendix A layout) -> the keys `S2Mel` reads."""
+    c = dict(base)
+    d, w, lr = y.get("DiT") or {}, y.get("wavenet") or {}, y.get("length_regulator") or {}
+    for src, dst in (("hidden_dim", "hidden_dim"), ("num_heads", "num_heads"), ("depth", "depth"), ("in_channels", "in_channels"), ("content_dim", "content_dim")):
+        if src in d:
+            c[dst] = d[src]
+    for src, dst in (("hidden_dim", "wavenet_hidden"), ("num_layers", "wavenet_layers"), ("kernel_size", "wavenet_kernel"), ("dilation_rate", "wavenet_dilation_rate")):
+        if src in w:
+            c[dst] = w[src]
+    if "channels" in lr:
+        c["lr_channels"] = lr["channels"]
+    if "in_channels" in lr:
+        c["lr_in_channels"] = lr["in_channels"]
+    if "sampling_ratios" in lr:
+        c["lr_n_blocks"] = len(lr["sampling_ratios"])
+    if "dim" in (y.get("style_encoder") or {}):
+        c["style_dim"] = y["style_encoder"]["dim"]
+    return c
+
+
 class Glue:
-    """Interface of the PyTorch-hosted stages.  All tensors on `device`."""
+    """Optional override of the PyTorch-hosted stages: a method that is implemented
+    replaces the built-in stage, one that raises NotImplementedError leaves the built-in in place.  All tensors on `device`."""
 
     def tokenize(self, text, max_text_tokens_per_segment, quick_streaming_tokens=0):
         """-> list of segments, each a list of text token ids (front.py:313-327,345-436; infer_v2.py:582-583,617)."""
@@ -65,7 +126,8 @@ class IndexTTS2:
     def __init__(self, cfg_path="models/IndexTTS/config.yaml", model_dir="models/IndexTTS", use_fp16=False, device=None,
                  use_cuda_kernel=None, use_deepspeed=False, *, glue=None, gpt_state_dict=None, bigvgan_state_dict=None,
                  s2mel_state_dict=None, gpt_cfg=None, bigvgan_cfg=None, cond_cfg=None, s2mel_cfg=None, tokenizer=None,
-                 max_seq=2048, max_frames=4096):
+                 max_seq=2048, max_frames=4096, w2v_bert=None, w2v_stats=None, semantic_codec_state_dict=None, codec_cfg=None,
+                 campplus_state_dict=None, emo_matrix=None, spk_matrix=None, emo_num=None):
         if device is None:
             if not torch.cuda.is_available():
                 raise RuntimeError("the HIP hot path needs a GPU (no CPU fallback); pass device='cuda:N'")
@@ -87,6 +149,7 @@ class IndexTTS2:
                 if k in cfg.get("gpt", {}):
                     gcfg[k] = cfg["gpt"][k]
         self.cfg = cfg
+        self.model_version = cfg.get("version")
         self.stop_mel_token = gcfg["stop_mel_token"]
         # reference precision: fp16 GPT under use_fp16 (infer_v2.py:79,88-89); here bf16 is the throughput mode
         self.gpt = GptEngine(gcfg, dtype="bf16" if use_fp16 else "f32", max_seq=max_seq, max_batch=3, device=self.device)
@@ -114,12 +177,79 @@ class IndexTTS2:
         if "conditioning_encoder.embed.conv.0.weight" in gpt_state_dict:
             from .conditioning import COND_CFG, Conditioning
 
-            self.cond = Conditioning(gpt_state_dict, COND_CFG if cond_cfg is None else cond_cfg, device=self.device)
+            if cond_cfg is None:
+                cond_cfg = dict(COND_CFG, model_dim=D)
+                for k in ("condition_module", "emo_condition_module"):
+                    if k in cfg.get("gpt", {}):
+                        cond_cfg[k] = {**cond_cfg[k], **{a: b for a, b in cfg["gpt"][k].items() if a in cond_cfg[k]}}
+                # widths the yaml does not spell out are read off the tensors
+                cond_cfg["input_size"] = 2 * gpt_state_dict["conditioning_encoder.embed.out.0.weight"].shape[1] // gpt_state_dict[
+                    "conditioning_encoder.embed.out.0.weight"].shape[0] + 1 if "input_size" not in cfg.get("gpt", {}) else cfg["gpt"]["input_size"]
+                cond_cfg["emo_dim"] = gpt_state_dict["emovec_layer.weight"].shape[1]
+                cond_cfg["cond_num"] = gpt_state_dict["perceiver_encoder.latents"].shape[0]
+            self.cond = Conditioning(gpt_state_dict, cond_cfg, device=self.device)
+        # ---- prompt-side models (prompt.py; infer_v2.py:114-152,168-188): given tensors, else the files of model_dir
+        from . import prompt as PR
+
+        missing = []
+        have = lambda *parts: os.path.exists(os.path.join(model_dir, *parts))
+        codec_cfg = dict(PR.CODEC_CFG if codec_cfg is None else codec_cfg)
+        for k in codec_cfg:
+            if k in (cfg.get("semantic_codec") or {}):
+                codec_cfg[k] = cfg["semantic_codec"][k]
+        if semantic_codec_state_dict is None and have("semantic_codec", "model.safetensors"):
+            from safetensors.torch import load_file
+
+            semantic_codec_state_dict = load_file(os.path.join(model_dir, "semantic_codec", "model.safetensors"))
+        self.semantic_codec = PR.SemanticCodec(semantic_codec_state_dict, codec_cfg, self.device) if semantic_codec_state_dict is not None else None
+        if self.semantic_codec is None:
+            missing.append("semantic_codec/model.safetensors")
         self.s2mel = None
+        if s2mel_state_dict is None and cfg.get("s2mel_checkpoint") and have(cfg["s2mel_checkpoint"]):
+            s2mel_state_dict = load_s2mel_checkpoint(os.path.join(model_dir, cfg["s2mel_checkpoint"]))
         if s2mel_state_dict is not None:
             from .s2mel import S2MEL_CFG, S2Mel
 
-            self.s2mel = S2Mel(s2mel_state_dict, S2MEL_CFG if s2mel_cfg is None else s2mel_cfg, device=self.device)
+            scfg = dict(S2MEL_CFG if s2mel_cfg is None else s2mel_cfg)
+            if s2mel_cfg is None and cfg.get("s2mel"):
+                scfg = _s2mel_cfg_from_yaml(cfg["s2mel"], scfg)
+            s2mel_state_dict = dict(s2mel_state_dict)
+            if "quantizer.codebook.weight" not in s2mel_state_dict and self.semantic_codec is not None:
+                # `semantic_codec.quantizer.vq2emb` (infer_v2.py:714) lives in the codec checkpoint, not in s2mel.pth
+                s2mel_state_dict.update(self.semantic_codec.s2mel_quantizer_tensors())
+                scfg.update(codebook_size=codec_cfg["codebook_size"], codebook_dim=codec_cfg["codebook_dim"], semantic_dim=codec_cfg["hidden_size"])
+            self.s2mel = S2Mel(s2mel_state_dict, scfg, device=self.device)
+        else:
+            missing.append(cfg.get("s2mel_checkpoint", "s2mel.pth"))
+        if w2v_bert is not None and not isinstance(w2v_bert, PR.W2vBert):
+            st = w2v_stats if w2v_stats is not None else {"mean": torch.zeros(1), "var": torch.ones(1)}
+            w2v_bert = PR.W2vBert(w2v_bert, st["mean"], torch.sqrt(st["var"]), device=self.device)
+        if w2v_bert is None and have("w2v-bert-2.0") and cfg.get("w2v_stat") and have(cfg["w2v_stat"]):
+            w2v_bert = PR.W2vBert.from_dir(os.path.join(model_dir, "w2v-bert-2.0"), os.path.join(model_dir, cfg["w2v_stat"]), self.device)
+        self.w2v_bert = w2v_bert
+        if w2v_bert is None:
+            missing.append("w2v-bert-2.0/ + " + str(cfg.get("w2v_stat", "wav2vec2bert_stats.pt")))
+        if campplus_state_dict is None and have("campplus_cn_common.bin"):
+            campplus_state_dict = torch.load(os.path.join(model_dir, "campplus_cn_common.bin"), map_location="cpu", weights_only=True)
+        self.campplus = PR.CamPlus(campplus_state_dict, self.device) if campplus_state_dict is not None else None
+        if self.campplus is None:
+            missing.append("campplus_cn_common.bin")
+        self.prompt = None
+        if not missing:
+            sp = ((cfg.get("s2mel") or {}).get("preprocess_params") or {})
+            spect = sp.get("spect_params") or {}
+            mel_args = dict(n_fft=spect.get("n_fft", 1024), win_size=spect.get("win_length", 1024), hop_size=spect.get("hop_length", 256),
+                            num_mels=spect.get("n_mels", 80), sampling_rate=sp.get("sr", 22050), fmin=spect.get("fmin", 0),
+                            fmax=None if spect.get("fmax", "None") == "None" else 8000)
+            self.prompt = PR.PromptEncoder(self.w2v_bert, self.semantic_codec, self.campplus, self.s2mel, self.device, mel_args)
+        self.missing_glue = missing
+        # emotion matrices (infer_v2.py:168-176): rows grouped per emotion by emo_num
+        self.emo_num = list(emo_num if emo_num is not None else cfg.get("emo_num", []))
+        for name, given, key in (("emo_matrix", emo_matrix, "emo_matrix"), ("spk_matrix", spk_matrix, "spk_matrix")):
+            m = given
+            if m is None and cfg.get(key) and have(cfg[key]):
+                m = torch.load(os.path.join(model_dir, cfg[key]), map_location="cpu", weights_only=True)
+            setattr(self, name, torch.split(m.to(self.device), self.emo_num) if m is not None and self.emo_num else None)
         # text front-end (row N4; infer_v2.py:161-165): a given tokenizer, else model_dir/<dataset.bpe_model> with the
         # reference's normaliser (needs WeText, as there), else `glue.tokenize`
         self.tokenizer = tokenizer
@@ -128,8 +258,12 @@ class IndexTTS2:
             from .front import TextNormalizer, TextTokenizer
 
             self.normalizer = TextNormalizer()
-            self.tokenizer = TextTokenizer(bpe, self.normalizer)
-            logger.info(f"bpe model loaded from: {bpe}")
+            try:
+                self.normalizer.load()  # infer_v2.py:162-163: the WeText verbalisers, imported as the reference imports them
+                self.tokenizer = TextTokenizer(bpe, self.normalizer)
+                logger.info(f"bpe model loaded from: {bpe}")
+            except ImportError as e:
+                self.missing_glue.append(f"text normalizer (WeTextProcessing not importable: {e})")
         # prompt caches (infer_v2.py:190-197)
         self.cache_spk_audio_prompt = None
         self.cache_spk = None
@@ -154,24 +288,46 @@ class IndexTTS2:
         return out
 
     def _prepare_gpt_inputs(self, conds_latent, text_ids):
-        """UnifiedVoice.prepare_gpt_inputs (model_v2.py:598-661): -> fake ids [1,P], embeds [1,P-1,D], mask [1,P]."""
-        c = self.gpt_cfg
-        t = torch.as_tensor(text_ids, dtype=torch.long, device=self.device).reshape(-1)
-        L = t.numel()
-        t = t[(t != c["stop_text_token"]) & (t != c["start_text_token"])]
-        t = torch.cat((t.new_tensor([c["start_text_token"]]), t, t.new_tensor([c["stop_text_token"]])))
-        temb = self.text_embedding[t] + self.text_pos_embedding[: t.numel()]
-        pad = L + 2 - t.numel()
-        parts = [conds_latent, temb]
-        if pad > 0:
-            parts.insert(0, torch.zeros(pad, self.model_dim, device=self.device))
-        embeds = torch.cat(parts, 0)
-        P = embeds.shape[0] + 1
+        """-> fake ids [1, P], embeds [1, P-1, D], mask [1, P] (model_v2.py:598-661; one implementation: pipeline.prepare_gpt_inputs)."""
+        embeds, pad, P = prepare_gpt_inputs(self.gpt_cfg, self.text_embedding, self.text_pos_embedding, conds_latent, text_ids)
         mask = torch.ones(1, P, dtype=torch.long, device=self.device)
         mask[0, :pad] = 0
         fake = torch.ones(1, P, dtype=torch.long, device=self.device)
-        fake[0, -1] = c["start_mel_token"]
+        fake[0, -1] = self.gpt_cfg["start_mel_token"]
         return fake, embeds.unsqueeze(0), mask
+
+    # ---- the once-per-prompt stages: an injected glue method wins, else the built-in prompt encoder, else a clear error
+    def _stage(self, name, builtin):
+        fn = getattr(self.glue, name, None) if self.glue is not None else None
+        if fn is not None and getattr(type(self.glue), name, None) is not getattr(Glue, name, None):
+            return fn
+        if builtin is None:
+            raise NotImplementedError(
+                f"IndexTTS2.infer: stage '{name}' has no weights (missing under model_dir: {', '.join(self.missing_glue) or 'emotion matrices'}) "
+                f"and no glue= override was given; nothing is downloaded or faked (INTEGRATION.md lists the model_dir layout)")
+        return builtin
+
+    def ready(self):
+        """True when infer() can synthesise from audio: every stage has weights or an injected override."""
+        try:
+            self._stage("speaker", self.prompt.speaker if self.prompt else None)
+            self._stage("emotion", self.prompt.emotion if self.prompt else None)
+            if self.tokenizer is None:
+                self._stage("tokenize", None)
+            if self.s2mel is None:
+                self._stage("s2mel", None)
+            if self.cond is None:
+                self._stage("merge_emovec", None)
+        except NotImplementedError:
+            return False
+        return True
+
+    def _builtin_emo_mix(self, emo_vector, style, use_random):
+        from .prompt import emo_vector_mix
+
+        if self.emo_matrix is None or self.spk_matrix is None:
+            return None
+        return emo_vector_mix(emo_vector, style, self.emo_matrix, self.spk_matrix, self.emo_num, use_random)
 
     # ------------------------------------------------------------------ API
     def infer(self, spk_audio_prompt, text, output_path, emo_audio_prompt=None, emo_alpha=1.0, emo_vector=None,
@@ -190,13 +346,11 @@ class IndexTTS2:
     def infer_generator(self, spk_audio_prompt, text, output_path, emo_audio_prompt=None, emo_alpha=1.0, emo_vector=None,
                         use_emo_text=False, emo_text=None, use_random=False, interval_silence=200, verbose=False,
                         max_text_tokens_per_segment=120, stream_return=False, quick_streaming_tokens=0, **generation_kwargs):
-        if self.glue is None:
-            raise NotImplementedError(
-                "IndexTTS2.infer needs the PyTorch glue stages (audio features, conditioners, s2mel, text front-end), which this "
-                "repository does not build (DESIGN.md section 7); pass glue=<voice_tts_amd.infer_v2.Glue implementation>")
         logger.info("Starting inference...")
         start_time = time.perf_counter()
         glue = self.glue
+        speaker_fn = self._stage("speaker", self.prompt.speaker if self.prompt else None)
+        emotion_fn = self._stage("emotion", self.prompt.emotion if self.prompt else None)
         if use_emo_text:
             raise NotImplementedError("use_emo_text needs the Qwen emotion model (infer_v2.py:481-488), out of scope")
         if emo_vector is not None:
@@ -207,15 +361,16 @@ class IndexTTS2:
         if emo_audio_prompt is None:
             emo_audio_prompt = spk_audio_prompt
             emo_alpha = 1.0
-        if self.cache_spk is None or self.cache_spk_audio_prompt is not spk_audio_prompt:
-            self.cache_spk = glue.speaker(spk_audio_prompt)
+        if self.cache_spk is None or not _same_prompt(self.cache_spk_audio_prompt, spk_audio_prompt):
+            self.cache_spk = speaker_fn(spk_audio_prompt)
             self.cache_spk_audio_prompt = spk_audio_prompt
         spk = self.cache_spk
         emovec_mat = weight_sum = None
         if emo_vector is not None:
-            emovec_mat, weight_sum = glue.emo_vector_mix(emo_vector, spk["style"], use_random)
-        if self.cache_emo_cond is None or self.cache_emo_audio_prompt is not emo_audio_prompt:
-            self.cache_emo_cond = glue.emotion(emo_audio_prompt)
+            mix = self._stage("emo_vector_mix", (lambda v, st, r: self._builtin_emo_mix(v, st, r)) if self.emo_matrix is not None else None)
+            emovec_mat, weight_sum = mix(emo_vector, spk["style"], use_random)
+        if self.cache_emo_cond is None or not _same_prompt(self.cache_emo_audio_prompt, emo_audio_prompt):
+            self.cache_emo_cond = emotion_fn(emo_audio_prompt)
             self.cache_emo_audio_prompt = emo_audio_prompt
         emo_cond_emb = self.cache_emo_cond
 
@@ -229,7 +384,7 @@ class IndexTTS2:
             segments = [self.tokenizer.convert_tokens_to_ids(sent) for sent in
                         self.tokenizer.split_segments(text_tokens_list, max_text_tokens_per_segment, quick_streaming_tokens=quick_streaming_tokens)]
         else:
-            segments = glue.tokenize(text, max_text_tokens_per_segment, quick_streaming_tokens)
+            segments = self._stage("tokenize", None)(text, max_text_tokens_per_segment, quick_streaming_tokens)
         # generation kwargs and their defaults (infer_v2.py:598-606); do_sample is popped and then forced True (:648)
         generation_kwargs.pop("do_sample", True)
         top_p = generation_kwargs.pop("top_p", 0.8)
@@ -258,10 +413,10 @@ class IndexTTS2:
             req_cond32 = self.cond.get_conditioning(sc.transpose(1, 2), ls)[0]
             gpt_gen_time += time.perf_counter() - m0
         def conds_for_segment():
-            emovec = req_emovec if req_emovec is not None else glue.merge_emovec(spk["spk_cond_emb"], emo_cond_emb, emo_alpha)
+            emovec = req_emovec if req_emovec is not None else self._stage("merge_emovec", None)(spk["spk_cond_emb"], emo_cond_emb, emo_alpha)
             if emo_vector is not None:
                 emovec = emovec_mat + (1 - weight_sum) * emovec
-            cond32 = req_cond32 if req_cond32 is not None else glue.get_conditioning(spk["spk_cond_emb"])
+            cond32 = req_cond32 if req_cond32 is not None else self._stage("get_conditioning", None)(spk["spk_cond_emb"])
             # inference_speech (model_v2.py:693-734)
             return torch.cat((cond32 + emovec.reshape(1, -1), self.speed_emb[1:2], self.speed_emb[0:1]), 0)
 
@@ -308,6 +463,8 @@ class IndexTTS2:
                 codes = out[:, trunc:]
                 torch.cuda.synchronize(self.device)
                 gpt_gen_time += time.perf_counter() - m0
+            if codes.shape[1] == 0:  # no room left to generate (max_mel_tokens == 0 or a prompt as long as max_seq)
+                raise RuntimeError(f"no mel codes could be generated for segment {seg_index} (max_mel_tokens={max_mel_tokens}, max_seq={self.gpt.max_seq})")
             if not has_warned and bool((codes[:, -1] != self.stop_mel_token).any()):
                 warnings.warn(f"WARN: generation stopped due to exceeding `max_mel_tokens` ({max_mel_tokens}). "
                               f"Input text tokens: {text_tokens.shape[0]}. Consider reducing `max_text_tokens_per_segment`"
@@ -333,7 +490,7 @@ class IndexTTS2:
                 mel = self.s2mel(latent, codes, code_lens, spk["prompt_condition"], spk["ref_mel"], spk["style"],
                                  n_timesteps=25, inference_cfg_rate=0.7)
             else:
-                mel = glue.s2mel(latent, codes, code_lens, spk)
+                mel = self._stage("s2mel", None)(latent, codes, code_lens, spk)
             torch.cuda.synchronize(self.device)
             s2mel_time += time.perf_counter() - m0
 

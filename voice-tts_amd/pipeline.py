@@ -28,6 +28,25 @@ def arena_tensor(ptr, nbytes, device):
     return torch.as_tensor(_RawDeviceBuffer(ptr, nbytes), device=device)
 
 
+def prepare_gpt_inputs(cfg, text_embedding, text_pos_embedding, conds_latent, text_ids):
+    """UnifiedVoice.prepare_gpt_inputs (model_v2.py:598-661), one sequence: start/stop text ids found INSIDE the text are
+    dropped and made up for by zero rows on the left (mask 0 there), then [start] text [stop] is embedded.
+
+    conds_latent [34, D] device; text_ids int [L].  Returns (embeds [P-1, D], n_left_pad, P)."""
+    device = text_embedding.device
+    t = torch.as_tensor(text_ids, dtype=torch.long, device=device).reshape(-1)
+    L = t.numel()
+    t = t[(t != cfg["stop_text_token"]) & (t != cfg["start_text_token"])]
+    t = torch.cat((t.new_tensor([cfg["start_text_token"]]), t, t.new_tensor([cfg["stop_text_token"]])))
+    temb = text_embedding[t] + text_pos_embedding[: t.numel()]
+    pad = L + 2 - t.numel()
+    parts = [conds_latent.to(device, torch.float32), temb]
+    if pad > 0:
+        parts.insert(0, torch.zeros(pad, temb.shape[1], device=device))
+    embeds = torch.cat(parts, 0)
+    return embeds, pad, embeds.shape[0] + 1
+
+
 class HotPath:
     def __init__(self, gpt_cfg=None, bigvgan_cfg=None, dtype="bf16", device="cuda:0", max_batch=2, max_seq=2048,
                  max_frames=2048, fast_sin=False):
@@ -65,23 +84,8 @@ class HotPath:
 
     # ------------------------------------------------------------------ G0
     def prepare_gpt_inputs(self, conds_latent, text_ids):
-        """UnifiedVoice.prepare_gpt_inputs (model_v2.py:598-661), one sequence.
-
-        conds_latent [34, D] device; text_ids int [L].  Returns (embeds [P-1, D], n_left_pad, P).
-        """
-        c = self.gpt_cfg
-        t = torch.as_tensor(text_ids, dtype=torch.long, device=self.device).reshape(-1)
-        L = t.numel()
-        valid = (t != c["stop_text_token"]) & (t != c["start_text_token"])
-        t = t[valid]
-        t = torch.cat((t.new_tensor([c["start_text_token"]]), t, t.new_tensor([c["stop_text_token"]])))
-        temb = self.text_embedding[t] + self.text_pos_embedding[: t.numel()]
-        pad = L + 2 - t.numel()
-        parts = [conds_latent.to(self.device, torch.float32), temb]
-        if pad > 0:
-            parts.insert(0, torch.zeros(pad, temb.shape[1], device=self.device))
-        embeds = torch.cat(parts, 0)
-        return embeds, pad, embeds.shape[0] + 1
+        """-> (embeds [P-1, D], n_left_pad, P); see the module-level `prepare_gpt_inputs`."""
+        return prepare_gpt_inputs(self.gpt_cfg, self.text_embedding, self.text_pos_embedding, conds_latent, text_ids)
 
     def conds_latent(self, cond32, emo_vec):
         """inference_speech (model_v2.py:693-696)."""

@@ -149,6 +149,11 @@ def create_app(model_factory=default_model_factory):
     def health_check():
         if state["model"] is None:
             raise HTTPException(status_code=503, detail="Model not loaded")
+        # a model whose prompt-side stages have no weights loads but cannot synthesise: that is not "healthy"
+        ready = getattr(state["model"], "ready", None)
+        if callable(ready) and not ready():
+            raise HTTPException(status_code=503, detail="Model loaded without its prompt-side weights: "
+                                + ", ".join(getattr(state["model"], "missing_glue", []) or ["text tokenizer"]))
         return {"status": "healthy", "model_loaded": True, "deepspeed_enabled": False}
 
     @app.get("/debug/worker-info")
