@@ -1,32 +1,42 @@
 #!/usr/bin/env python
-"""bench.py -- throughput of the MI355X hot path on BASELINE.json's metric.
+"""bench.py -- throughput of the MI355X hot path on BASELINE.json's metric (RTF / audio-seconds per second).
 
-Workload (configs[1], SURVEY.md 8(d) "Config 2"): ONE /tts request = 200-token zh text ->
-2 segments x 100 tokens (prompt P = 137 rows), 5 s speaker prompt already reduced to
-`conds_latent`; greedy fixed-length decode n = 1100 codes per segment (stop token
-suppressed: random weights never emit EOS), the latent GPT forward per segment, and
-BigVGAN over floor(1.72 n) = 1892 mel frames per segment -> 44.13 s of audio.
-The stages `north_star` leaves to PyTorch glue (conditioning encoders, s2mel CFM) are not
-built in this repo and are NOT in the timed region: their outputs (`conds_latent`, mel)
-are synthetic tensors resident in HBM, so `value` is the hot-path-only rate.
+Default workload (BASELINE configs[1], SURVEY.md 8(d) "Config 2"): ONE /tts request per GPU = 200-token zh text ->
+2 segments x 100 tokens (prompt P = 137 rows), 5 s speaker prompt -> the conditioning encoders (conformer + perceiver, torch
+glue) -> greedy fixed-length decode of n = 1100 codes per segment, both segments decoded together (stop token suppressed:
+random weights never emit EOS) -> the latent GPT forward per segment -> s2mel (length regulator + 25-step CFM/DiT, torch glue
+with HIP attention / row kernels) -> BigVGAN over floor(1.72 n) = 1892 mel frames per segment -> 44.13 s of audio.  ALL of
+these stages are inside the timed region; what stays synthetic is what the reference caches per speaker prompt (w2v-bert
+features, CAM++ style, prompt condition, reference mel): seeded HBM-resident tensors of the production shapes.
 
-One "step" = one such request.  Weak scaling: every rank serves its own request
-(process-per-GPU sharding, gunicorn_config.py:43-60); RCCL is used only to broadcast the
-packed weight arenas from rank 0 at load.
+One "step" = one such request per rank.  Weak scaling: every rank serves its own request (process-per-GPU sharding,
+gunicorn_config.py:43-60); RCCL only broadcasts the weights from rank 0 at load (the packed GPT / BigVGAN arenas and one packed
+buffer of the glue weights -- voice-tts_amd/sharding.py).  `--gpus N` without a torchrun environment starts its own N rank
+processes (a child `python -m torch.distributed.run`, before this process touches a GPU).
+
+`--workload mixed64` is BASELINE configs[3] (SURVEY config 4): 64 requests of 50-400 characters with distinct prompts,
+request i -> rank i mod N, each rank's segments decoded through the continuous-batching scheduler; the whole job is one step
+(strong scaling).  `--decode beam`, `--dtype f32`, `--bigvgan-only`, `--concurrency R` select the other BASELINE configs.
+
+The default N=1 line also carries, under "extra", figures the driver would otherwise never see: the config-5 BigVGAN
+microbench, the served-default 3-beam request, the fp32 (parity-mode) request and the decode step per batch size.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
+import numpy as np  # noqa: E402,F401
+import torch  # noqa: E402
+
+PEAK_HBM, PEAK_F32 = 8000.0, 157.3  # GB/s, TFLOP/s (MI355X_MICROARCH.md)
 
 
 def host_cores():
@@ -45,32 +55,54 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--workload", default="request", choices=["request", "mixed64"], help="request: BASELINE configs[1] (the judged line); "
+                    "mixed64: configs[3] -- 64 mixed-length requests, request i -> rank i mod N, continuous batching on each rank")
     ap.add_argument("--tokens", type=int, default=100, help="text tokens per segment")
     ap.add_argument("--codes", type=int, default=1100, help="mel codes per segment (11 per char)")
     ap.add_argument("--segments", type=int, default=2)
+    ap.add_argument("--slots", type=int, default=0, help="decode slots for --concurrency / mixed64 (0 = the engine's maximum)")
     ap.add_argument("--no-s2mel", action="store_true", help="leave the PyTorch-glue s2mel stage out of the timed region (feed synthetic mels)")
-    ap.add_argument("--concurrency", type=int, default=1, help="requests in flight per GPU (config 3 style): their segments share the decode "
-                    "slots through the continuous-batching scheduler (row N3); 1 = BASELINE config[1], the judged line")
+    ap.add_argument("--concurrency", type=int, default=1, help="requests in flight per GPU: their segments share the decode slots through the "
+                    "continuous-batching scheduler (row N3); 1 = BASELINE configs[1], the judged line")
     ap.add_argument("--no-cond", action="store_true", help="leave the conditioning encoders out of the timed region (feed a synthetic conds_latent)")
-    ap.add_argument("--decode", default="greedy", choices=["greedy", "beam"], help="greedy: BASELINE config[1] (the judged line); beam: the served "
-                    "default of config[2] -- 3-beam beam-sample, top_k 30, top_p 0.8, temperature 0.8 -- one segment at a time")
-    ap.add_argument("--bigvgan-only", action="store_true", help="BASELINE config[4]: 1000-frame random mel -> waveform microbench (20 warm-up + 100 timed)")
+    ap.add_argument("--decode", default="greedy", choices=["greedy", "beam"], help="greedy: BASELINE configs[1] (the judged line); beam: the served "
+                    "default of configs[2] -- 3-beam beam-sample, top_k 30, top_p 0.8, temperature 0.8 -- one segment at a time")
+    ap.add_argument("--bigvgan-only", action="store_true", help="BASELINE configs[4]: 1000-frame random mel -> waveform microbench (20 warm-up + 100 timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra figures of the default line (config 5, beam, fp32, step per batch size)")
+    return ap.parse_args(argv)
 
 
-def bigvgan_microbench(WR, dev, rank):
-    """BASELINE config[4] / SURVEY 8(d) config 5: mel ~ N(-4, 2) clipped to [-11.5, 2], fp32 [1, 80, 1000] -> [1, 1, 256000]."""
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N rank processes ourselves.  This process has not touched a GPU
+    (importing torch does not), it only waits for the child launcher and passes its output and exit code on."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("starting ranks: " + " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+# ================================================================================================ stage microbenches
+def bigvgan_microbench(WR, dev, model=None):
+    """BASELINE configs[4] / SURVEY 8(d) config 5: mel ~ N(-4, 2) clipped to [-11.5, 2], fp32 [1, 80, 1000] -> [1, 1, 256000]."""
     from voice_tts_amd.bigvgan import BigVGAN
 
-    m = BigVGAN(WR.BIGVGAN_CFG, max_frames=1024, device=dev).load_state_dict(WR.make_bigvgan_weights(WR.BIGVGAN_CFG, seed=1234))
+    m = model if model is not None else BigVGAN(WR.BIGVGAN_CFG, max_frames=1024, device=dev).load_state_dict(WR.make_bigvgan_weights(WR.BIGVGAN_CFG, seed=1234))
     F = 1000
     mel = (torch.randn(1, 80, F, generator=torch.Generator().manual_seed(6)) * 2 - 4).clamp(-11.5, 2).to(dev)
     for _ in range(20):
@@ -84,20 +116,152 @@ def bigvgan_microbench(WR, dev, rank):
     ms = e0.elapsed_time(e1) / 100
     fl = m.flops(1, F)
     alg_bytes = 732.8e6  # weights once + stage-boundary activations once + mel + wav, per 1000 frames
-    if rank == 0:
-        print(json.dumps({"metric": "bigvgan_ms_per_1000_frames", "value": round(ms, 3), "unit": "ms", "n_gpus": 1, "steps": 100, "warmup": 20,
-                          "higher_is_better": False, "dtype": "f32", "data": "synthetic", "audio_seconds_per_second": round(256 * F / 22050 / (ms * 1e-3), 1),
-                          "config": {"workload": "BigVGAN-only: 1000-frame random mel -> 256000 samples (11.61 s)"},
-                          "roofline": {"bound": "mfma", "achieved": round(fl / ms / 1e9, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / 157.3, 3),
-                                       "flops": fl, "hbm_GBps_algorithmic": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "hbm_peak_GBps": 8000.0}}), flush=True)
+    return {"metric": "bigvgan_ms_per_1000_frames", "value": round(ms, 3), "unit": "ms", "n_gpus": 1, "steps": 100, "warmup": 20,
+            "higher_is_better": False, "dtype": "f32", "data": "synthetic", "audio_seconds_per_second": round(256 * F / 22050 / (ms * 1e-3), 1),
+            "config": {"workload": "BigVGAN-only: 1000-frame random mel -> 256000 samples (11.61 s)"},
+            "roofline": {"bound": "mfma", "achieved": round(fl / ms / 1e9, 1), "peak": PEAK_F32, "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / PEAK_F32, 3),
+                         "flops": fl, "hbm_GBps_algorithmic": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "hbm_peak_GBps": PEAK_HBM}}
 
 
+def decode_step_by_batch(hp, P, batches, n_steps=256):
+    """Decode step time per batch size B (weights are read once for B sequences): B prompts of P rows, `n_steps` greedy steps,
+    HIP events on the launch stream.  Context runs from P to P + n_steps."""
+    out = {}
+    D = hp.gpt.D
+    emb = (torch.randn(P - 1, D, generator=torch.Generator().manual_seed(1)) * 0.5).to(hp.device)
+    for B in batches:
+        if B > hp.gpt.max_batch:
+            continue
+        for b in range(B):
+            hp.gpt.prefill(b, emb, 0)
+        hp.gpt.decode(B, 16, repetition_penalty=10.0, suppress_stop=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        hp.gpt.decode(B, n_steps, repetition_penalty=10.0, suppress_stop=True)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n_steps
+        by = hp.gpt.step_bytes(B, P + 16 + n_steps // 2)
+        out[str(B)] = {"us": round(us, 1), "alg_bytes": by, "achieved_GBps": round(by / us / 1e3, 1), "frac": round(by / us / 1e3 / PEAK_HBM, 4),
+                       "us_per_sequence": round(us / B, 1)}
+    return out
+
+
+# ================================================================================================ the request
+class Workload:
+    """Synthetic inputs of one rank, resident in HBM before the timed region, and the request loop over the HotPath."""
+
+    def __init__(self, args, hp, dev, rank, use_s2mel, use_cond):
+        import voice_tts_amd.weights as WR
+
+        self.args, self.hp, self.dev, self.use_s2mel, self.use_cond = args, hp, dev, use_s2mel, use_cond
+        self.D = WR.GPT_CFG["model_dim"]
+        self.Tref = 430  # 5 s speaker prompt -> 430 reference mel frames, 249 w2v-bert frames (SURVEY 8(d) config 2)
+        self.g = torch.Generator().manual_seed(100 + rank)
+        self.stage_ms = {"gpt_gen": 0.0, "gpt_forward": 0.0, "s2mel": 0.0, "bigvgan": 0.0}
+
+    def prompt(self):
+        """Stand-ins for what the reference caches per speaker prompt (infer_v2.py:508-545)."""
+        g, dev = self.g, self.dev
+        return dict(spk_cond_emb=torch.randn(1, 249, 1024, generator=g).to(dev), prompt_condition=torch.randn(1, self.Tref, 512, generator=g).to(dev),
+                    ref_mel=(torch.randn(1, 80, self.Tref, generator=g) * 2 - 4).clamp(-11.5, 2).to(dev), style=torch.randn(1, 192, generator=g).to(dev),
+                    conds=(torch.randn(34, self.D, generator=g) * 0.5).to(dev))
+
+    def conds(self, pr):
+        if not self.use_cond:
+            return pr["conds"]
+        cl = self.hp.conds_from_prompt(pr["spk_cond_emb"])  # merge_emovec + get_conditioning (infer_v2.py:629-635), once per request
+        # synthetic encoder weights give arbitrary latent statistics; keep the GPT prefix at the scale it is built for
+        return cl * (0.5 / cl.std().clamp_min(1e-6))
+
+    def post(self, hp, pr, cl, text, codes, acc):
+        """latent pass -> s2mel -> BigVGAN -> int16 on the host, one segment; stage times accumulate in `acc`."""
+        tick = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
+        ta = tick()
+        lat = hp.latent(cl, text, codes)
+        tb = tick()
+        frames = int(len(codes) * 1.72)
+        if self.use_s2mel:  # 25 Euler steps x CFG batch 2 over T = 430 + frames, fp32 (infer_v2.py:713-731)
+            mel = hp.s2mel(lat, codes, pr["prompt_condition"], pr["ref_mel"], pr["style"]).clamp(-11.5, 2.0)  # synthetic weights: keep the log-mel range
+        else:
+            mel = (torch.randn(1, 80, frames, generator=torch.Generator().manual_seed(frames)) * 2 - 4).clamp(-11.5, 2).to(self.dev)
+        tc = tick()
+        wav = hp.vocode(mel).to(torch.int16).cpu()  # wav.cpu() per segment, int16 truncation (infer_v2.py:744,781)
+        td = tick()
+        assert lat.shape == (len(codes), self.D) and wav.shape[-1] == frames * 256
+        acc["gpt_forward"] += (tb - ta) * 1e3
+        acc["s2mel"] += (tc - tb) * 1e3
+        acc["bigvgan"] += (td - tc) * 1e3
+
+
+def make_hotpath(args, dev, dtype, max_batch, max_seq, max_frames, share=None):
+    from voice_tts_amd.pipeline import HotPath
+
+    hp = HotPath(dtype=dtype, device=dev, max_batch=max_batch, max_seq=max_seq, max_frames=max_frames)
+    if share is not None:  # a second decode engine (beam / fp32 figures) over the same vocoder and glue
+        hp.bigvgan = share.bigvgan
+        hp.text_embedding, hp.text_pos_embedding, hp.speed_emb = share.text_embedding, share.text_pos_embedding, share.speed_emb
+        for n in ("s2mel_model", "cond_model"):
+            if hasattr(share, n):
+                setattr(hp, n, getattr(share, n))
+    return hp
+
+
+def run_request(wl, hp, pr, texts, n_codes, mode, R=1, acc=None):
+    """One /tts request (or R of them sharing the decode slots).  mode: greedy | beam."""
+    acc = wl.stage_ms if acc is None else acc
+    tick = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
+    t0 = tick()
+    cl = wl.conds(pr)
+    prompts = [hp.prepare_gpt_inputs(cl, t)[:2] for t in texts]
+    if R > 1:
+        many = hp.generate_many([(e, p, n_codes) for _ in range(R) for (e, p) in prompts], fixed_length=True, repetition_penalty=10.0)
+    elif mode == "beam":  # served default (infer_v2.py:598-606): the beams of one segment occupy the slots, segments in turn
+        many = []
+        for e, p in prompts:
+            hp.gpt.prefill(0, e, p)
+            hp.gpt.beam_begin(3)
+            hp.gpt.beam_decode(n_codes, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=True, seed=7)
+            many.append(hp.gpt.beam_read(n_codes)[0][:n_codes])
+    elif len(prompts) <= hp.gpt.max_batch:
+        many = hp.generate(prompts, n_codes, repetition_penalty=10.0, fixed_length=True)
+    else:
+        many = hp.generate_many([(e, p, n_codes) for (e, p) in prompts], fixed_length=True, repetition_penalty=10.0)
+    t1 = tick()
+    acc["gpt_gen"] += (t1 - t0) * 1e3
+    assert all(len(c) == n_codes for c in many)
+    for r in range(R):
+        for s, t in enumerate(texts):
+            wl.post(hp, pr, cl, t, many[r * len(texts) + s], acc)
+    return many
+
+
+def run_mixed(wl, hp, reqs, prompts, texts, acc):
+    """configs[3] on one rank: every request's conditioning, all segments through the scheduler, then the post stages."""
+    tick = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
+    t0 = tick()
+    cls = [wl.conds(pr) for pr in prompts]
+    segs, owner = [], []
+    for i, toks in enumerate(reqs):
+        for s, n in enumerate(toks):
+            e, p, _ = hp.prepare_gpt_inputs(cls[i], texts[i][s])
+            segs.append((e, p, 11 * n))
+            owner.append((i, s))
+    codes = hp.generate_many(segs, fixed_length=True, repetition_penalty=10.0)
+    acc["gpt_gen"] += (tick() - t0) * 1e3
+    for (i, s), c in zip(owner, codes):
+        wl.post(hp, prompts[i], cls[i], texts[i][s], c, acc)
+
+
+# ================================================================================================ main
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -108,118 +272,81 @@ def main():
     torch.cuda.set_device(dev)
 
     import voice_tts_amd.weights as WR
-    from voice_tts_amd.pipeline import HotPath, audio_seconds
+    from voice_tts_amd import _lib, sharding
+    from voice_tts_amd.pipeline import audio_seconds
 
     if args.bigvgan_only:
-        return bigvgan_microbench(WR, dev, rank)
+        out = bigvgan_microbench(WR, dev)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return
     D = WR.GPT_CFG["model_dim"]
     n_seg, n_tok, n_codes = args.segments, args.tokens, args.codes
-    frames = int(n_codes * 1.72)
-    P = 34 + n_tok + 2 + 1
     R = max(1, args.concurrency)
-    hp = HotPath(dtype=args.dtype, device=dev, max_batch=4 if R > 1 else (3 if args.decode == "beam" else (max(2, n_seg) if n_seg <= 4 else 4)), max_seq=P + n_codes + 64,
-                 max_frames=frames)
+    mixed = args.workload == "mixed64"
+    engine_max = _lib.max_batch()
+    slots = min(args.slots or engine_max, engine_max)
+    if mixed:
+        all_reqs = sharding.mixed_requests()
+        mine = sharding.my_requests(len(all_reqs), rank, world)  # request i -> rank i mod N (gunicorn_config.py:53-54)
+        reqs = [all_reqs[i] for i in mine]
+        max_tok = max(max(r) for r in all_reqs)
+        P, max_codes, max_batch = 34 + max_tok + 2 + 1, 11 * max_tok, slots
+    else:
+        P, max_codes = 34 + n_tok + 2 + 1, n_codes
+        max_batch = slots if R > 1 else (3 if args.decode == "beam" else min(max(2, n_seg), engine_max))
+    frames = int(max_codes * 1.72)
+    hp = make_hotpath(args, dev, args.dtype, max_batch, P + max_codes + 64, frames)
 
-    # ---- load: rank 0 builds the (synthetic, seeded) weights, RCCL broadcasts the packed arenas
+    # ---- load: rank 0 builds the (synthetic, seeded) weights; RCCL broadcasts the packed arenas and ONE packed glue buffer
     t_load = time.time()
     Wg = Wb = None
-    use_s2mel = not args.no_s2mel
+    use_s2mel, use_cond = not args.no_s2mel, not args.no_cond
     if rank == 0:
         Wg = WR.make_gpt_weights(WR.GPT_CFG, seed=1234)
         Wb = WR.make_bigvgan_weights(WR.BIGVGAN_CFG, seed=1234)
         hp.load(Wg, Wb)
+    glue_shapes, Wglue = [], {}
     if use_s2mel:
-        # PyTorch glue stage (row N1): every rank regenerates the same seeded weights (98 M params, plain torch tensors)
         import voice_tts_amd.s2mel as S2
 
-        hp.attach_s2mel(S2.make_s2mel_weights(S2.S2MEL_CFG, seed=1234))
-    use_cond = not args.no_cond
+        glue_shapes += S2.s2mel_shapes(S2.S2MEL_CFG)
+        if rank == 0:
+            Wglue.update(S2.make_s2mel_weights(S2.S2MEL_CFG, seed=1234))
     if use_cond:
-        # PyTorch glue stage (row N2): conformer + perceiver conditioning encoders (338 M params, seeded per rank alike)
         import voice_tts_amd.conditioning as CD
 
-        hp.attach_conditioning(CD.make_cond_weights(CD.COND_CFG, seed=1234))
+        glue_shapes += CD.cond_shapes(CD.COND_CFG)
+        if rank == 0:
+            Wglue.update(CD.make_cond_weights(CD.COND_CFG, seed=1234))
     if world > 1:
-        for t in hp.broadcast_tensors():
-            dist.broadcast(t, src=0)
+        sharding.broadcast_weights(hp.broadcast_tensors(), src=0)
         if rank != 0:
             hp.adopt()
+        Wglue = sharding.broadcast_tensor_dict(Wglue if rank == 0 else None, glue_shapes, dev, src=0, rank=rank)
+    if use_s2mel:
+        hp.attach_s2mel({k: v for k, v in Wglue.items() if k.split(".")[0] in ("cfm", "length_regulator", "gpt_layer", "quantizer")})
+    if use_cond:
+        hp.attach_conditioning(Wglue)
     torch.cuda.synchronize()
     t_load = time.time() - t_load
     log(f"weights loaded in {t_load:.1f}s")
 
-    # ---- synthetic request, resident in HBM before the timed region (seeded per rank)
-    g = torch.Generator().manual_seed(100 + rank)
-    conds = [(torch.randn(34, D, generator=g) * 0.5).to(dev) for _ in range(n_seg)]
-    # 5 s speaker prompt -> 249 w2v-bert frames: stand-in for the cached, normalised layer-17 features
-    spk_cond_emb = torch.randn(1, 249, 1024, generator=g).to(dev)
-    texts = [torch.randint(2, 12000, (n_tok,), generator=g) for _ in range(n_seg)]
-    mels = [(torch.randn(1, 80, frames, generator=g) * 2 - 4).clamp(-11.5, 2).to(dev) for _ in range(n_seg)]
-    # 5 s speaker prompt -> 430 reference mel frames: stand-ins for the cached prompt features
-    Tref = 430
-    prompt_condition = torch.randn(1, Tref, 512, generator=g).to(dev)
-    ref_mel = (torch.randn(1, 80, Tref, generator=g) * 2 - 4).clamp(-11.5, 2).to(dev)
-    style = torch.randn(1, 192, generator=g).to(dev)
-    audio_s = audio_seconds([n_codes] * n_seg)
+    wl = Workload(args, hp, dev, rank, use_s2mel, use_cond)
+    if mixed:
+        prompts = [wl.prompt() for _ in reqs]  # all prompts distinct: the speaker cache never hits (infer_v2.py:508)
+        texts = [[torch.randint(2, 12000, (n,), generator=wl.g) for n in r] for r in reqs]
+        audio_s = sum(audio_seconds([11 * n for n in r]) for r in reqs)
+        step = lambda acc: run_mixed(wl, hp, reqs, prompts, texts, acc)
+    else:
+        pr = wl.prompt()
+        texts = [torch.randint(2, 12000, (n_tok,), generator=wl.g) for _ in range(n_seg)]
+        audio_s = R * audio_seconds([n_codes] * n_seg)
+        step = lambda acc: run_request(wl, hp, pr, texts, n_codes, args.decode, R, acc)
 
-    stage_ms = {"gpt_gen": 0.0, "gpt_forward": 0.0, "s2mel": 0.0, "bigvgan": 0.0}
-
-    def request(timed):
-        def tick():
-            torch.cuda.synchronize()
-            return time.perf_counter()
-
-        t0 = tick()
-        if use_cond:  # merge_emovec + get_conditioning (infer_v2.py:629-635, model_v2.py:684-696), once per request
-            cl = hp.conds_from_prompt(spk_cond_emb)
-            # synthetic encoder weights give arbitrary latent statistics; keep the GPT prefix at the scale it is built for
-            cl = cl * (0.5 / cl.std().clamp_min(1e-6))
-            for s in range(n_seg):
-                conds[s] = cl
-        prompts = [hp.prepare_gpt_inputs(conds[s], texts[s])[:2] for s in range(n_seg)]
-        if R > 1:  # R requests in flight: all their segments go through the continuous-batching scheduler
-            many = hp.generate_many([(e, p, n_codes) for _ in range(R) for (e, p) in prompts], fixed_length=True, repetition_penalty=10.0)
-            codes = many[:n_seg]
-        elif args.decode == "beam":  # served default (infer_v2.py:598-606): beams of one segment occupy the slots, segments in turn
-            codes = []
-            for e, p in prompts:
-                hp.gpt.prefill(0, e, p)
-                hp.gpt.beam_begin(3)
-                hp.gpt.beam_decode(n_codes, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=True, seed=7)
-                codes.append(hp.gpt.beam_read(n_codes)[0][:n_codes])
-        else:
-            codes = hp.generate(prompts, n_codes, repetition_penalty=10.0, fixed_length=True)
-        t1 = tick()
-        t2 = t2b = t3 = t1
-        for r in range(R):  # the post-decode stages stay per segment (and per request)
-            ta = tick()
-            rc = codes if R == 1 else many[r * n_seg:(r + 1) * n_seg]
-            lats = [hp.latent(conds[s], texts[s], rc[s]) for s in range(n_seg)]
-            tb = tick()
-            if use_s2mel:  # 25 Euler steps x CFG batch 2 over T = 430 + 1892 frames, fp32 (infer_v2.py:713-731)
-                seg_mels = [hp.s2mel(lats[s], rc[s], prompt_condition, ref_mel, style) for s in range(n_seg)]
-                # synthetic weights give arbitrary mel statistics; keep the vocoder input in the log-mel range it is built for
-                seg_mels = [m.clamp(-11.5, 2.0) for m in seg_mels]
-            else:
-                seg_mels = mels
-            tc_ = tick()
-            wavs = []
-            for s in range(n_seg):
-                w = hp.vocode(seg_mels[s])
-                wavs.append(w.to(torch.int16).cpu())  # wav.cpu() per segment, int16 truncation (infer_v2.py:744,781)
-            td = tick()
-            t2, t2b, t3 = t2 + (tb - ta), t2b + (tc_ - ta), t3 + (td - ta)
-        if timed:
-            stage_ms["gpt_gen"] += (t1 - t0) * 1e3
-            stage_ms["gpt_forward"] += (t2 - t1) * 1e3
-            stage_ms["s2mel"] += (t2b - t2) * 1e3
-            stage_ms["bigvgan"] += (t3 - t2b) * 1e3
-        assert all(len(c) == n_codes for c in codes) and all(l.shape == (n_codes, D) for l in lats)
-        assert all(w.shape[-1] == frames * 256 for w in wavs)
-        return codes
-
+    scratch = dict(wl.stage_ms)
     for i in range(args.warmup):
-        request(False)
+        step(dict(scratch))
         log(f"warmup {i} done")
 
     def barrier():
@@ -230,23 +357,22 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        request(True)
+        step(wl.stage_ms)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    total_audio = audio_s * args.steps
+    if dist is not None:  # sum of the units over ranks, max of the times
+        total_audio, elapsed = sharding.gather_throughput(total_audio, elapsed, device=dev)
     log(f"timed region: {elapsed:.2f}s for {args.steps} steps")
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * R * audio_s * args.steps / elapsed
+    value = total_audio / elapsed
+    stage_ms = wl.stage_ms
 
-    # ---- roofline of the dominant kernel: the decode-step FC GEMV (largest weight stream per launch),
-    # timed live with events on the launch stream, cycling the 24 layers (314 MB bf16 > Infinity Cache)
+    # ---- roofline of the dominant kernel: the decode-step FC GEMV (largest weight stream per launch), timed live with
+    # events on the launch stream, cycling the 24 layers (314 MB bf16 > Infinity Cache)
     roofline = None
     if rank == 0 and not args.no_roofline:
-        B = n_seg if n_seg <= hp.gpt.max_batch else 1
+        B = min(n_seg, hp.gpt.max_batch) if not mixed and R == 1 and args.decode == "greedy" else hp.gpt.max_batch
         es = 2 if args.dtype == "bf16" else 4
         L = WR.GPT_CFG["layers"]
         alg_bytes = 4 * D * D * es + 4 * D * 4 + B * D * 4 + B * 4 * D * 4
@@ -270,44 +396,47 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (reps * L)
         achieved = alg_bytes / (us * 1e-6) / 1e9
-        # HBM traffic per launch of the same kernel from the committed PMC passes (tools/pmc_traffic.py; separate
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 FETCH correction) -- null if no pass matches
-        traffic = None
+        # HBM traffic per launch of the same kernel: NOT measured in this run -- read from the committed PMC passes of this
+        # command (tools/pmc_traffic.py; separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 FETCH correction)
+        traffic, traffic_src = None, None
         try:
             import glob
 
             wt = "__hip_bfloat16" if args.dtype == "bf16" else "float"
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[::-1]:
                 ks = json.load(open(f))["kernels"]
-                hit = [v for k, v in ks.items() if f"gemv_reg_kernel<{wt}, 1280, 2, 2, {B}, 0, 2," in k]
+                hit = [v for k, v in ks.items() if "gemv" in k and wt in k and f" {B}, " in k and v.get("role") == "fc"] or \
+                      [v for k, v in ks.items() if f"gemv_reg_kernel<{wt}, 1280, 2, 2, {B}, 0, 2," in k]
                 if hit:
-                    traffic = round(hit[0]["hbm_bytes_per_launch"])
+                    traffic, traffic_src = round(hit[0]["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
                     break
         except Exception:
             traffic = None
-        S_mid = P + n_codes // 2
+        S_mid = P + max_codes // 2
         step_bytes = hp.gpt.step_bytes(B, S_mid)
-        step_us = stage_ms["gpt_gen"] / args.steps * 1e3 / n_codes  # includes the conditioning encoders, both prefills and the host syncs (pessimistic by ~3 %)
         roofline = {
-            "bound": "hbm", "kernel": f"gemv_reg_kernel<{args.dtype},K=1280,IN_LN,EPI_GELU> (decode LN2+FC, B={B})",
-            "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-            "traffic": traffic, "bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3),
-            "decode_step": {"alg_bytes": step_bytes, "us": round(step_us, 1), "achieved_GBps": round(step_bytes / step_us / 1e3, 1),
-                            "frac": round(step_bytes / step_us / 1e3 / 8000.0, 4), "kernels_per_step": 5 * L + 2},
+            "bound": "hbm", "kernel": f"decode LN2+FC GEMV ({args.dtype}, K=1280 -> 5120, gelu epilogue), B={B}",
+            "achieved": round(achieved, 1), "peak": PEAK_HBM, "unit": "GB/s", "frac": round(achieved / PEAK_HBM, 4),
+            "traffic": traffic, "traffic_source": (f"{traffic_src}: separate rocprofv3 --pmc passes of this command, not measured in this run" if traffic_src else None),
+            "bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3),
         }
+        if not mixed and R == 1:
+            step_us = stage_ms["gpt_gen"] / args.steps * 1e3 / n_codes / (n_seg if args.decode == "beam" else 1)
+            roofline["decode_step"] = {"alg_bytes": step_bytes, "us": round(step_us, 1), "achieved_GBps": round(step_bytes / step_us / 1e3, 1),
+                                       "frac": round(step_bytes / step_us / 1e3 / PEAK_HBM, 4), "kernels_per_step": 5 * L + 2,
+                                       "note": "gpt_gen / codes: includes the conditioning encoders, the prefills and the host syncs (pessimistic by ~3 %)"}
 
-    # ---- the other stages against their rooflines (fp32 MFMA peak 157.3 TFLOP/s): BigVGAN from its timed stage, the DiT
-    # attention kernel timed live with events on the launch stream (report the binding fraction per family)
+    # ---- the other stages against their rooflines (fp32 MFMA peak): BigVGAN from its timed stage, the DiT attention kernel
+    # timed live with events on the launch stream (report the binding fraction per family)
     stage_roof = None
-    if rank == 0 and not args.no_roofline:
-        PEAK_F32 = 157.3
+    if rank == 0 and not args.no_roofline and not mixed:
         bv_tf = hp.bigvgan.flops(1, frames) * n_seg * R / (stage_ms["bigvgan"] / args.steps * 1e-3) / 1e12
         stage_roof = {"bigvgan": {"bound": "mfma", "achieved": round(bv_tf, 1), "peak": PEAK_F32, "unit": "TFLOP/s", "frac": round(bv_tf / PEAK_F32, 3),
                                   "flops_per_segment": hp.bigvgan.flops(1, frames)}}
         if use_s2mel:
             from voice_tts_amd.s2mel import attn_full
 
-            Ta = Tref + frames
+            Ta = wl.Tref + frames
             qkv = torch.randn(2, Ta, 3, 8, 64, device=dev)
             for _ in range(3):
                 attn_full(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])
@@ -322,9 +451,44 @@ def main():
             stage_roof["s2mel_attention"] = {"bound": "mfma", "kernel": "attn_full_f32_kernel + merge (B=2, H=8, T=%d)" % Ta, "achieved": round(fl / us_a / 1e6, 1),
                                              "peak": PEAK_F32, "unit": "TFLOP/s", "frac": round(fl / us_a / 1e6 / PEAK_F32, 3), "us_per_call": round(us_a, 1)}
 
+    # ---- extra figures of the default line (driver-visible): config 5, the served 3-beam default, fp32 parity mode, step per B
+    extra = None
+    default_line = world == 1 and not mixed and R == 1 and args.decode == "greedy" and args.dtype == "bf16" and not args.no_extra
+    if rank == 0 and default_line:
+        extra = {}
+        log("extra: BigVGAN config-5 microbench")
+        mb = bigvgan_microbench(WR, dev, hp.bigvgan)
+        extra["bigvgan_config5"] = {"ms_per_1000_frames": mb["value"], "audio_seconds_per_second": mb["audio_seconds_per_second"],
+                                    "TFLOPs": mb["roofline"]["achieved"], "frac_fp32_mfma_peak": mb["roofline"]["frac"]}
+        one_audio = audio_seconds([n_codes] * n_seg)
+        for name, dtype, mode, mb_ in (("beam3_bf16", "bf16", "beam", 3), ("greedy_fp32", "f32", "greedy", min(max(2, n_seg), engine_max))):
+            log(f"extra: {name} request")
+            hp2 = make_hotpath(args, dev, dtype, mb_, P + n_codes + 64, frames, share=hp)
+            hp2.gpt.load_state_dict(Wg)
+            acc = {k: 0.0 for k in stage_ms}
+            run_request(wl, hp2, pr, texts, n_codes, mode, 1, dict(acc))
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            reps = 2
+            for _ in range(reps):
+                run_request(wl, hp2, pr, texts, n_codes, mode, 1, acc)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - tq) / reps
+            extra[name] = {"rtf": round(dt / one_audio, 5), "audio_seconds_per_second": round(one_audio / dt, 2), "ms_per_request": round(dt * 1e3, 1),
+                           "stage_ms": {k: round(v / reps, 1) for k, v in acc.items()},
+                           "decode_us_per_step": round(acc["gpt_gen"] / reps * 1e3 / n_codes / (n_seg if mode == "beam" else 1), 1)}
+            del hp2
+            torch.cuda.empty_cache()
+        log("extra: decode step per batch size")
+        hpB = make_hotpath(args, dev, "bf16", engine_max, P + 64 + 512, 64, share=hp)
+        hpB.gpt.load_state_dict(Wg)
+        extra["decode_step_by_batch"] = decode_step_by_batch(hpB, P, [b for b in (1, 2, 4, 8, 16) if b <= engine_max])
+        del hpB
+        torch.cuda.empty_cache()
+
     # ---- CPU baseline: the oracle (port of the reference's CPU path) on a bounded sample
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not mixed:
         from oracle import gpt as OG
         from oracle import vocoder as OV
 
@@ -332,7 +496,9 @@ def main():
         cores = torch.get_num_threads()
         log(f"cpu baseline on {cores} threads")
         orc = OG.GptOracle(Wg, WR.GPT_CFG["layers"], WR.GPT_CFG["heads"])
-        fake, emb, mask = orc.prepare_gpt_inputs(conds[0].cpu(), texts[0])
+        g = wl.g
+        cl0 = pr["conds"].cpu()
+        fake, emb, mask = orc.prepare_gpt_inputs(cl0, texts[0])
         tc = time.perf_counter()
         logits, past = orc.prefill(emb, mask)
         t_prefill = time.perf_counter() - tc
@@ -347,12 +513,13 @@ def main():
         log(f"cpu decode {t_step*1e3:.1f} ms/step")
         n_lat = 600
         tc = time.perf_counter()
-        orc.latent_pass(conds[0].cpu(), texts[0], torch.randint(0, 8192, (n_lat,)))
+        orc.latent_pass(cl0, texts[0], torch.randint(0, 8192, (n_lat,)))
         t_lat_row = (time.perf_counter() - tc) / (34 + n_tok + 2 + n_lat + 2)
         log(f"cpu latent {t_lat_row*1e3:.2f} ms/row")
         f_s = 256
+        mel_s = (torch.randn(1, 80, f_s, generator=g) * 2 - 4).clamp(-11.5, 2)
         tc = time.perf_counter()
-        OV.bigvgan_forward(mels[0][:, :, :f_s].cpu(), Wb)
+        OV.bigvgan_forward(mel_s, Wb)
         t_frame = (time.perf_counter() - tc) / f_s
         t_s2 = 0.0
         s2_note = ""
@@ -363,10 +530,10 @@ def main():
             cpu_s2 = S2.S2Mel(S2.make_s2mel_weights(S2.S2MEL_CFG, seed=1234), S2.S2MEL_CFG, device="cpu")
             lat_c = torch.randn(1, n_codes, D, generator=g)
             tc = time.perf_counter()
-            cpu_s2(lat_c, torch.randint(0, 8192, (1, n_codes), generator=g), torch.tensor([n_codes]), prompt_condition.cpu(), ref_mel.cpu(),
-                   style.cpu(), n_timesteps=1)
+            cpu_s2(lat_c, torch.randint(0, 8192, (1, n_codes), generator=g), torch.tensor([n_codes]), pr["prompt_condition"].cpu(), pr["ref_mel"].cpu(),
+                   pr["style"].cpu(), n_timesteps=1)
             t_s2 = (time.perf_counter() - tc) * 25
-            s2_note = f", s2mel 1 of 25 Euler steps at T={Tref + frames} ({t_s2 / 25:.2f} s/step)"
+            s2_note = f", s2mel 1 of 25 Euler steps at T={wl.Tref + frames} ({t_s2 / 25:.2f} s/step)"
             log(f"cpu s2mel {t_s2 / 25:.2f} s/step")
         t_cond = 0.0
         cond_note = ""
@@ -375,7 +542,7 @@ def main():
             import voice_tts_amd.conditioning as CD
 
             cpu_cd = CD.Conditioning(CD.make_cond_weights(CD.COND_CFG, seed=1234), CD.COND_CFG, device="cpu")
-            sc = spk_cond_emb.cpu()
+            sc = pr["spk_cond_emb"].cpu()
             ls = torch.tensor([sc.shape[-1]])
             tc = time.perf_counter()
             with torch.no_grad():
@@ -385,31 +552,42 @@ def main():
             cond_note = f", conditioning encoders on 249 frames ({t_cond:.2f} s per segment)"
             log(f"cpu conditioning {t_cond:.2f} s")
         est = n_seg * (t_cond + t_prefill + n_codes * t_step + (P + n_codes + 2) * t_lat_row + t_s2 + frames * t_frame)
-        cpu = {"value": round(audio_s / est, 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
+        one_audio = audio_seconds([n_codes] * n_seg)
+        cpu = {"value": round(one_audio / est, 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
                "sample": f"oracle fp32: 1 prefill of {P} rows ({t_prefill:.2f}s), {n_dec} decode steps ({t_step*1e3:.1f} ms/step), "
                          f"latent pass on {n_lat} codes ({t_lat_row*1e3:.2f} ms/row), BigVGAN {f_s} frames ({t_frame*1e3:.1f} ms/frame){s2_note}{cond_note}; "
                          f"extrapolated linearly to the full request ({est:.0f}s est.)",
-               "rtf": round(est / audio_s, 3)}
+               "rtf": round(est / one_audio, 3)}
 
     if rank == 0:
+        if mixed:
+            n_segs = sum(len(r) for r in all_reqs)
+            workload = (f"64 concurrent /tts requests, 50-400 characters (seed 5, {sum(sum(r) for r in all_reqs)} tokens in {n_segs} segments of <= 120 tokens), "
+                        f"distinct 5 s prompts, request i -> rank i mod {world}; on each rank: conditioning encoders per request, all segments through the "
+                        f"continuous-batching scheduler ({max_batch} decode slots, greedy fixed-length, 11 codes per token), then latent forward, "
+                        + ("s2mel (25-step CFM), " if use_s2mel else "s2mel skipped, ") + "BigVGAN per segment; one step = the whole 64-request job")
+        else:
+            workload = ((f"1 /tts request per GPU: " if R == 1 else f"{R} concurrent /tts requests per GPU (segments share the decode slots, continuous batching B<={max_batch}), each ")
+                        + f"{n_seg}x{n_tok}-token zh text segments (200-char utterance), "
+                        + ("conditioning encoders on 249 prompt frames (conformer + perceiver, PyTorch-ROCm glue, fp32), " if use_cond else "")
+                        + (f"greedy fixed-length decode {n_codes} codes/segment batched B={min(n_seg, max_batch)}, " if args.decode == "greedy" else
+                           f"3-beam beam-sample (top_k 30, top_p 0.8, T 0.8, theta 10) fixed-length decode {n_codes} codes/segment, segments in turn, ")
+                        + "latent GPT forward, "
+                        + ("s2mel (length regulator + 25-step CFM/DiT, PyTorch-ROCm glue, fp32, 430-frame prompt), " if use_s2mel else "s2mel skipped (synthetic mel), ")
+                        + f"BigVGAN {frames} frames/segment -> {audio_s / R:.2f} s audio; the per-prompt features the reference caches (w2v-bert, CAM++, "
+                        f"semantic codec, reference mel; built in voice-tts_amd/prompt.py) enter as synthetic HBM-resident tensors of the production shapes"
+                        + ("" if use_cond else " and so does conds_latent"))
         out = {
             "metric": "audio_seconds_per_second", "value": round(value, 3), "unit": "audio-s/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "rtf": round(elapsed / (R * audio_s * args.steps), 5),
+            "scaling": "strong" if mixed else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            # weak: wall seconds per audio second of ONE request stream; mixed64: of the whole job
+            "rtf": round(elapsed / total_audio * (1 if mixed else world), 5),
             "config": {
-                "workload": (f"1 /tts request per GPU: " if R == 1 else f"{R} concurrent /tts requests per GPU (segments share the decode slots, continuous batching B<=4), each ")
-                            + f"{n_seg}x{n_tok}-token zh text segments (200-char utterance), "
-                            + ("conditioning encoders on 249 prompt frames (conformer + perceiver, PyTorch-ROCm glue, fp32), " if use_cond else "")
-                            + (f"greedy fixed-length decode {n_codes} codes/segment batched B={n_seg}, " if args.decode == "greedy" else
-                               f"3-beam beam-sample (top_k 30, top_p 0.8, T 0.8, theta 10) fixed-length decode {n_codes} codes/segment, segments in turn, ")
-                            + "latent GPT forward, "
-                            + ("s2mel (length regulator + 25-step CFM/DiT, PyTorch-ROCm glue, fp32, 430-frame prompt), " if use_s2mel else "s2mel skipped (synthetic mel), ")
-                            + f"BigVGAN {frames} frames/segment -> {audio_s:.2f} s audio; prompt feature extraction (w2v-bert, CAM++, semantic "
-                            f"codec, reference mel) not built: spk_cond_emb / prompt_condition / ref_mel / style are synthetic HBM-resident inputs"
-                            + ("" if use_cond else " and so is conds_latent"),
-                "segments": n_seg, "text_tokens_per_segment": n_tok, "codes_per_segment": n_codes, "mel_frames_per_segment": frames,
-                "audio_seconds_per_request": round(audio_s, 3), "parallelism": f"request-per-GPU x{world}, RCCL weight broadcast at load",
+                "workload": workload,
+                "segments": n_seg if not mixed else n_segs, "text_tokens_per_segment": n_tok if not mixed else "50-400 chars / ceil(len/120)",
+                "codes_per_segment": n_codes if not mixed else "11 per token", "mel_frames_per_segment": frames if not mixed else "floor(1.72 codes)",
+                "audio_seconds_per_step": round(total_audio / args.steps, 3), "parallelism": f"request-per-GPU x{world}, RCCL weight broadcast at load",
                 "gpt_precision": f"{args.dtype} weights+KV, fp32 accumulate", "bigvgan_precision": "fp32 (fp32 MFMA)",
                 "s2mel": "torch fp32 glue + HIP attention / row kernels in the timed region" if use_s2mel else "excluded",
                 "conditioning": "torch fp32 glue in the timed region (inside gpt_gen)" if use_cond else "excluded",
@@ -418,6 +596,7 @@ def main():
             "load_s": round(t_load, 1),
             "roofline": roofline,
             "stage_rooflines": stage_roof,
+            "extra": extra,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

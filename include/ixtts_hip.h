@@ -235,6 +235,9 @@ int ixtts_gpt_bench_gemv(ixtts_gpt* h, int which, int layer, int batch, void* st
 /* Algorithmic HBM bytes of one decode step at batch B and context S. */
 double ixtts_gpt_step_bytes(const ixtts_gpt* h, int B, int S);
 
+/* Largest `max_batch` (decode slots decoded together, weights read once per step for all of them) this build supports. */
+int ixtts_gpt_max_batch(void);
+
 int ixtts_gpt_destroy(ixtts_gpt* h);
 
 #ifdef __cplusplus

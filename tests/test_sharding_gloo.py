@@ -31,9 +31,15 @@ def _worker(rank, world, port, q):
     if rank != 0:
         arenas = [torch.zeros_like(a) for a in arenas]
     sharding.broadcast_weights(arenas, src=0)
+    # glue weights: shapes known everywhere, tensors only on rank 0 -> one packed message
+    shapes = [("a.weight", (3, 5)), ("a.bias", (5,)), ("b", (2, 2, 2))]
+    W = {n: torch.randn(s, generator=g) for n, s in shapes} if rank == 0 else None
+    got = sharding.broadcast_tensor_dict(W, shapes, "cpu", src=0)
+    assert [tuple(got[n].shape) for n, _ in shapes] == [s for _, s in shapes]
+    glue_sum = float(sum(v.double().sum() for v in got.values()))
     mine = sharding.my_requests(7, rank, world)
     audio, elapsed = sharding.gather_throughput(10.0 * len(mine), 1.0 + rank)
-    q.put((rank, [int(a.sum()) if a.dtype == torch.uint8 else float(a.sum()) for a in arenas], mine, audio, elapsed))
+    q.put((rank, [int(a.sum()) if a.dtype == torch.uint8 else float(a.sum()) for a in arenas] + [glue_sum], mine, audio, elapsed))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -43,6 +49,9 @@ def test_broadcast_and_round_robin_world2():
 
     assert sharding.assign(7, 2) == [[0, 2, 4, 6], [1, 3, 5]]
     assert sharding.assign(3, 8) == [[0], [1], [2], [], [], [], [], []]
+    reqs = sharding.mixed_requests()
+    assert len(reqs) == 64 and all(50 <= sum(r) <= 400 and max(r) <= 120 and max(r) - min(r) <= 1 for r in reqs)
+    assert [len(r) for r in reqs] == [-(-sum(r) // 120) for r in reqs] and reqs == sharding.mixed_requests()  # seeded
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

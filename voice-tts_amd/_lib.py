@@ -81,6 +81,7 @@ SYMBOLS = {
     "ixtts_gpt_latent": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P]),
     "ixtts_gpt_bench_gemv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "ixtts_gpt_step_bytes": (C.c_double, [_P, C.c_int, C.c_int]),
+    "ixtts_gpt_max_batch": (C.c_int, []),
     "ixtts_gpt_destroy": (C.c_int, [_P]),
 }
 
@@ -118,6 +119,11 @@ def check(rc, what=""):
     if rc != 0:
         msg = lib().ixtts_last_error().decode(errors="replace")
         raise IxttsError(f"{what} failed with code {rc}: {msg}")
+
+
+def max_batch():
+    """Decode slots the engine can step together (a build constant of libixtts_hip.so)."""
+    return int(lib().ixtts_gpt_max_batch())
 
 
 def current_stream_ptr():

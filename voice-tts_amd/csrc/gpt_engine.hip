@@ -931,6 +931,8 @@ extern "C" int ixtts_gpt_bench_gemv(ixtts_gpt* h, int which, int layer, int batc
   return do_gemv_which(h, which, layer, batch, (hipStream_t)stream);
 }
 
+extern "C" int ixtts_gpt_max_batch(void) { return MAXB; }
+
 extern "C" double ixtts_gpt_step_bytes(const ixtts_gpt* h, int B, int S) {
   if (!h) return 0.0;
   const double D = h->D, FF = h->FF, V = h->V, L = h->L, es = (double)h->esize;

@@ -153,17 +153,33 @@ class IndexTTS2:
         self.stop_mel_token = gcfg["stop_mel_token"]
         # reference precision: fp16 GPT under use_fp16 (infer_v2.py:79,88-89); here bf16 is the throughput mode
         self.gpt = GptEngine(gcfg, dtype="bf16" if use_fp16 else "f32", max_seq=max_seq, max_batch=3, device=self.device)
-        self.bigvgan = BigVGAN(bcfg, use_cuda_kernel=True, max_frames=max_frames, device=self.device)
         if gpt_state_dict is None and cfg.get("gpt_checkpoint") and os.path.isfile(os.path.join(model_dir, cfg["gpt_checkpoint"])):
             gpt_state_dict = load_gpt_checkpoint(os.path.join(model_dir, cfg["gpt_checkpoint"]))
         if gpt_state_dict is None:
             raise FileNotFoundError("no GPT weights: pass gpt_state_dict=... or provide model_dir/gpt_checkpoint (checkpoint.py:25-34)")
         if bigvgan_state_dict is None:
-            p = os.path.join(model_dir, "bigvgan_generator.pt")
-            if os.path.isfile(p):
-                bigvgan_state_dict = load_bigvgan_checkpoint(p)
+            # `BigVGAN.from_pretrained(cfg.vocoder.name)` (infer_v2.py:154-158, bigvgan.py:436-479) resolves a LOCAL directory holding
+            # config.json + bigvgan_generator.pt (or the checkpoint file itself); a hub name is never fetched
+            voc = str((cfg.get("vocoder") or {}).get("name", ""))
+            cands = [os.path.join(model_dir, voc, "bigvgan_generator.pt"), os.path.join(voc, "bigvgan_generator.pt"), os.path.join(model_dir, voc),
+                     os.path.join(model_dir, "bigvgan_generator.pt")]
+            for p in cands:
+                if voc or p == cands[-1]:
+                    if os.path.isfile(p):
+                        bigvgan_state_dict = load_bigvgan_checkpoint(p)
+                        cj = os.path.join(os.path.dirname(p), "config.json")
+                        if bigvgan_cfg is None and os.path.isfile(cj):
+                            import json
+
+                            h = json.load(open(cj))
+                            tup = lambda v: tuple(tup(x) for x in v) if isinstance(v, list) else v
+                            bcfg.update({k: tup(v) for k, v in h.items() if k in bcfg})
+                        break
         if bigvgan_state_dict is None:
             raise FileNotFoundError("no BigVGAN weights: pass bigvgan_state_dict=... or provide model_dir/bigvgan_generator.pt")
+        if bigvgan_cfg is None and "conv_pre.weight" in bigvgan_state_dict:
+            bcfg["upsample_initial_channel"] = int(bigvgan_state_dict["conv_pre.weight"].shape[0])  # the one width the tensors fix
+        self.bigvgan = BigVGAN(bcfg, use_cuda_kernel=True, max_frames=max_frames, device=self.device)
         self.gpt.load_state_dict(gpt_state_dict)
         self.bigvgan.load_state_dict(bigvgan_state_dict)
         D = gcfg["model_dim"]
@@ -185,6 +201,9 @@ class IndexTTS2:
                 # widths the yaml does not spell out are read off the tensors
                 cond_cfg["input_size"] = 2 * gpt_state_dict["conditioning_encoder.embed.out.0.weight"].shape[1] // gpt_state_dict[
                     "conditioning_encoder.embed.out.0.weight"].shape[0] + 1 if "input_size" not in cfg.get("gpt", {}) else cfg["gpt"]["input_size"]
+                cond_cfg["perceiver_dim_head"] = gpt_state_dict["perceiver_encoder.layers.0.0.to_q.weight"].shape[0] // cond_cfg["condition_module"]["attention_heads"]
+                cond_cfg["perceiver_depth"] = len({k.split(".")[2] for k in gpt_state_dict if k.startswith("perceiver_encoder.layers.")})
+                cond_cfg["cnn_kernel"] = gpt_state_dict["conditioning_encoder.encoders.0.conv_module.depthwise_conv.weight"].shape[-1]
                 cond_cfg["emo_dim"] = gpt_state_dict["emovec_layer.weight"].shape[1]
                 cond_cfg["cond_num"] = gpt_state_dict["perceiver_encoder.latents"].shape[0]
             self.cond = Conditioning(gpt_state_dict, cond_cfg, device=self.device)

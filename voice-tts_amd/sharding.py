@@ -34,3 +34,41 @@ def gather_throughput(local_audio_seconds, local_elapsed, device=None, group=Non
     dist.all_reduce(a, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(e, op=dist.ReduceOp.MAX, group=group)
     return float(a.item()), float(e.item())
+
+
+def broadcast_tensor_dict(W, shapes, device, src=0, group=None, rank=None):
+    """Glue weights as ONE message: every rank knows `shapes` = [(name, shape)] (they follow from the config), rank `src` holds
+    the tensors `W`; they are packed into a single flat fp32 buffer on `device`, broadcast once, and handed back as views of that
+    buffer -- the other ranks pass W=None and never generate or read the weights themselves."""
+    import math
+
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group) if rank is None else rank
+    sizes = [int(math.prod(shape)) for _, shape in shapes]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    if rank == src:
+        o = 0
+        for (name, shape), n in zip(shapes, sizes):
+            assert tuple(W[name].shape) == tuple(shape), (name, tuple(W[name].shape), tuple(shape))
+            flat[o:o + n].copy_(W[name].reshape(-1))
+            o += n
+    dist.broadcast(flat, src=src, group=group)
+    out, o = {}, 0
+    for (name, shape), n in zip(shapes, sizes):
+        out[name] = flat[o:o + n].view(shape)
+        o += n
+    return out
+
+
+def mixed_requests(n_requests=64, lo=50, hi=400, seed=5, max_tokens_per_segment=120, codes_per_token=11):
+    """BASELINE configs[3] / SURVEY 8(d) config 4: `n_requests` texts of randint(lo, hi+1) characters (seed 5), one token per
+    character, split into ceil(len / 120) near-equal segments (what `split_segments` yields for unpunctuated text), 11 mel
+    codes per token.  -> [[tokens per segment of request 0], ...]"""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(lo, hi + 1, (n_requests,), generator=g).tolist()
+    out = []
+    for n in lens:
+        k = -(-n // max_tokens_per_segment)
+        out.append([n // k + (1 if i < n % k else 0) for i in range(k)])
+    return out
