@@ -22,9 +22,9 @@ def twin_cfgs():
 
     gcfg = WR.tiny_gpt_cfg(model_dim=1280, layers=2, heads=20, number_text_tokens=400)  # MyModel.gpt_layer is fixed 1280 -> ... -> 1024
     ccfg = CD.tiny_cond_cfg(model_dim=1280, input_size=HID, emo_dim=40, cond_num=32)
-    scfg = S2.tiny_s2mel_cfg(gpt_dim=1280, semantic_dim=HID, lr_in_channels=HID, codebook_size=64, style_dim=192, hidden_dim=128, num_heads=2,
+    scfg = S2.tiny_s2mel_cfg(gpt_dim=1280, semantic_dim=HID, lr_in_channels=HID, codebook_size=8194, style_dim=192, hidden_dim=128, num_heads=2,
                              wavenet_hidden=128, depth=3)
-    qcfg = dict(codebook_size=64, hidden_size=HID, codebook_dim=8, vocos_dim=24, vocos_intermediate_dim=48, vocos_num_layers=2)
+    qcfg = dict(codebook_size=8194, hidden_size=HID, codebook_dim=8, vocos_dim=24, vocos_intermediate_dim=48, vocos_num_layers=2)
     return gcfg, ccfg, scfg, qcfg, WR.tiny_bigvgan_cfg(64)
 
 

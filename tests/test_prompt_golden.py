@@ -207,7 +207,7 @@ def test_prompt_encoder_from_model_dir_files(tmp_path):
     assert not any(k.startswith("cfm.module.") for k in sd) and "cfm.estimator.x_embedder.weight_v" not in sd
     sd.update(codec.s2mel_quantizer_tensors())
     scfg = _s2mel_cfg_from_yaml(cfg["s2mel"], S2.S2MEL_CFG)
-    scfg.update(codebook_size=64, codebook_dim=8, semantic_dim=SM.HID)
+    scfg.update(codebook_size=8194, codebook_dim=8, semantic_dim=SM.HID)
     s2 = S2.S2Mel(sd, scfg, device="cpu")
     enc = PR.PromptEncoder(w2v, codec, cam, s2, "cpu")
     raw = SM.synthetic_wav_bytes(1.5, 24000)

@@ -505,6 +505,9 @@ class IndexTTS2:
             gpt_forward_time += time.perf_counter() - m0
 
             m0 = time.perf_counter()
+            if self.s2mel is not None and code_len and int(codes.max()) >= self.s2mel.W["quantizer.codebook.weight"].shape[0]:
+                # the reference would index its codebook out of range here (a device-side assert on a GPU): refuse on the host instead
+                raise ValueError(f"mel code {int(codes.max())} outside the semantic codec's codebook ({self.s2mel.W['quantizer.codebook.weight'].shape[0]} entries)")
             if self.s2mel is not None:  # infer_v2.py:713-731
                 mel = self.s2mel(latent, codes, code_lens, spk["prompt_condition"], spk["ref_mel"], spk["style"],
                                  n_timesteps=25, inference_cfg_rate=0.7)
