@@ -8,7 +8,8 @@
 
 namespace ixtts {
 
-constexpr int MAXB = 4;
+constexpr int MAXB = 16;       // decode slots stepped together: 1..4 on the register GEMVs, 5..16 ("wide" engines) on the matrix cores (gpt_wide.h)
+constexpr int MAXB_REG = 4;
 constexpr int STEPS_PER_GRAPH = 8;
 
 enum TKind { T_VEC = 0, T_MAT_T = 1, T_MAT_N = 2, T_EMB = 3 };
@@ -86,6 +87,7 @@ struct ixtts_gpt {
   unsigned* mlp_ctr = nullptr; // [L][8*32 + 32]: per-layer, per-XCD arrival counters (+ a timeout mark)
   float* h2 = nullptr;         // second residual buffer (IN_LN_PART publishes the completed stream into the other one)
   float* hc = nullptr;         // the residual buffer the launch being issued works on
+  bool wide = false;       // max_batch > MAXB_REG: every decode launch of this engine takes the MFMA GEMVs, whatever n_active is
   bool attn_split = true;  // IXTTS_ATTN=legacy turns the split-S kernel off (A/B timing, fallback test)
   int attn_bucket = ixtts::NBKT;  // bucket the graph being captured is built for
   int host_prompt_len[ixtts::MAXB + 2];

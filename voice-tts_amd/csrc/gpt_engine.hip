@@ -19,6 +19,7 @@
 
 #include "gpt_engine.h"
 #include "gpt_kernels.h"
+#include "gpt_wide.h"
 
 using namespace ixtts;
 
@@ -247,7 +248,7 @@ static void launch_sampler(ixtts_gpt* h, int n_active, hipStream_t st) {
     case 2: return FN<WT, KVT, DD, 2>(__VA_ARGS__);          \
     case 3: return FN<WT, KVT, DD, 3>(__VA_ARGS__);          \
     case 4: return FN<WT, KVT, DD, 4>(__VA_ARGS__);          \
-    default: set_error("batch %d unsupported (1..4)", B); return IXTTS_ERR_ARG; \
+    default: set_error("batch %d unsupported on the register GEMVs (1..4)", B); return IXTTS_ERR_ARG; \
   }
 #define DISPATCH(FN, h, B, ...)                                                              \
   do {                                                                                       \
@@ -260,9 +261,68 @@ static void launch_sampler(ixtts_gpt* h, int n_active, hipStream_t st) {
     }                                                                                        \
   } while (0)
 
-static int do_forward_layers(ixtts_gpt* h, int B, int slot0, hipStream_t st) { DISPATCH(forward_layers, h, B, h, slot0, st); }
-static int do_head(ixtts_gpt* h, int B, int slot0, float* norm_out, hipStream_t st) { DISPATCH(gemv_head, h, B, h, slot0, norm_out, st); }
+
+// ------------------------------------------------------------------------------------ wide engines (gpt_wide.h)
+// max_batch > 4: bf16 only.  Rows per workgroup: one workgroup per CU where the matrix allows (N / 256 rows), at most 16 * NT.
+template <int K, int NT, int INP, int EPI, int NW = 4>
+static int launch_wide(const void* wt, const void* xin, const float* bias, void* out, int N, int B, int slot0, int out_stride, ixtts_gpt* h,
+                       void* kc, void* vc, const float* ln_w, const float* ln_b, hipStream_t st) {
+  const int rpw = std::max(1, std::min(16 * NT, ceil_div(N, 256)));
+  hipLaunchKernelGGL((gemv_wide_kernel<K, NT, INP, EPI, bf16, NW>), dim3(ceil_div(N, rpw)), dim3(64 * NW), 0, st, reinterpret_cast<const bf16*>(wt), xin, bias, out, N,
+                     rpw, B, slot0, out_stride, h->smax, kc, vc, (const int*)h->cur_len, h->H, ln_w, ln_b);
+  return IXTTS_OK;
+}
+
+template <int D>
+static int wide_which(ixtts_gpt* h, int which, int l, int B, int slot0, hipStream_t st) {
+  const LayerOff& o = h->lo[std::min(l, h->L - 1)];
+  const size_t lstride = (size_t)h->slots * D * h->smax * sizeof(bf16);
+  switch (which) {
+    case 0:
+      return launch_wide<D, 1, WIN_LN, EPI_QKV>(A_PTR(o.wqkv), h->h, A_F32(o.bqkv), h->q, 3 * D, B, slot0, D, h, (uint8_t*)h->kc + l * lstride,
+                                                 (uint8_t*)h->vc + l * lstride, nullptr, nullptr, st);
+    case 1:
+      return launch_wide<D, 1, WIN_PLAIN, EPI_RESID>(A_PTR(o.wo), h->att, A_F32(o.bo), h->h, D, B, slot0, D, h, nullptr, nullptr, nullptr, nullptr, st);
+    case 2:
+      return launch_wide<D, 2, WIN_LN, EPI_GELU>(A_PTR(o.wfc), h->h, A_F32(o.bfc), h->ff, 4 * D, B, slot0, 4 * D, h, nullptr, nullptr, nullptr, nullptr, st);
+    case 3:
+      return launch_wide<4 * D, 1, WIN_FF, EPI_RESID, (D == 1280 ? 8 : 4)>(A_PTR(o.wpr), h->ff, A_F32(o.bpr), h->h, D, B, slot0, D, h, nullptr, nullptr, nullptr, nullptr, st);
+    case 4:
+      return launch_wide<D, 2, WIN_LN2, EPI_LOGITS>(A_PTR(h->whead), h->h, A_F32(h->bhead), h->logits, h->V, B, slot0, h->V, h, nullptr, nullptr,
+                                                    A_F32(h->lnf_w), A_F32(h->lnf_b), st);
+  }
+  set_error("wide_which: %d", which);
+  return IXTTS_ERR_ARG;
+}
+
+// sampler / prefill leave the token's embedding in h->h; one workgroup per (head, slot) sweeps the whole context (the split-S
+// partials would have to be re-read by every out-proj workgroup: 21 KB per sequence)
+template <int D>
+static int forward_layers_wide(ixtts_gpt* h, int B, int slot0, hipStream_t st) {
+  const size_t lstride = (size_t)h->slots * D * h->smax * sizeof(bf16);
+  h->hc = h->h;
+  for (int l = 0; l < h->L; ++l) {
+    IX_TRY(wide_which<D>(h, 0, l, B, slot0, st));
+    hipLaunchKernelGGL((attn_decode_kernel<bf16, 8, 4>), dim3(h->H, 1, B), dim3(512), 0, st, h->q, (const void*)((uint8_t*)h->kc + l * lstride),
+                       (const void*)((uint8_t*)h->vc + l * lstride), h->cur_len, h->valid_from, h->smax, h->H, slot0, D, h->att, 1 IXTTS_TRACE_ARG);
+    IX_TRY(wide_which<D>(h, 1, l, B, slot0, st));
+    IX_TRY(wide_which<D>(h, 2, l, B, slot0, st));
+    IX_TRY(wide_which<D>(h, 3, l, B, slot0, st));
+  }
+  IX_HIP(hipGetLastError());
+  return IXTTS_OK;
+}
+
+static int do_forward_layers(ixtts_gpt* h, int B, int slot0, hipStream_t st) {
+  if (h->wide) return h->D == 1280 ? forward_layers_wide<1280>(h, B, slot0, st) : forward_layers_wide<128>(h, B, slot0, st);
+  DISPATCH(forward_layers, h, B, h, slot0, st);
+}
+static int do_head(ixtts_gpt* h, int B, int slot0, float* norm_out, hipStream_t st) {
+  if (h->wide) return h->D == 1280 ? wide_which<1280>(h, 4, 0, B, slot0, st) : wide_which<128>(h, 4, 0, B, slot0, st);
+  DISPATCH(gemv_head, h, B, h, slot0, norm_out, st);
+}
 static int do_gemv_which(ixtts_gpt* h, int which, int l, int B, hipStream_t st) {
+  if (h->wide) return h->D == 1280 ? wide_which<1280>(h, which, l, B, 0, st) : wide_which<128>(h, which, l, B, 0, st);
   switch (which) {
     case 0: DISPATCH(gemv_qkv, h, B, h, l, 0, st);
     case 1: DISPATCH(gemv_out, h, B, h, l, 0, st);
@@ -288,6 +348,7 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   IX_ARG(c->layers > 0 && c->n_mel_codes > 0 && c->n_mel_pos > 2 && c->max_seq > 8, "gpt_create: bad sizes");
   IX_ARG(c->max_batch >= 1 && c->max_batch <= MAXB, "gpt_create: max_batch %d (1..%d)", c->max_batch, MAXB);
   IX_ARG(c->weight_dtype == IXTTS_DTYPE_F32 || c->weight_dtype == IXTTS_DTYPE_BF16, "gpt_create: weight_dtype");
+  IX_ARG(c->max_batch <= MAXB_REG || c->weight_dtype == IXTTS_DTYPE_BF16, "gpt_create: max_batch %d > %d runs on the bf16 matrix cores: needs bf16 weights", c->max_batch, MAXB_REG);
   IX_ARG(c->start_mel_token >= 0 && c->start_mel_token < c->n_mel_codes && c->stop_mel_token >= 0 && c->stop_mel_token < c->n_mel_codes, "gpt_create: start/stop token out of range");
   auto* h = new (std::nothrow) ixtts_gpt();
   if (!h) return IXTTS_ERR_NOMEM;
@@ -405,6 +466,9 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   hipMemset(h->logits, 0, (size_t)S * V * 4);
   if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
   if (const char* e = getenv("IXTTS_ATTN")) h->attn_split = strcmp(e, "legacy") != 0;
+  h->wide = c->max_batch > MAXB_REG;
+  if (const char* e = getenv("IXTTS_WIDE")) h->wide = h->wide || (strcmp(e, "1") == 0 && c->weight_dtype == IXTTS_DTYPE_BF16);  // A/B: small batches on the MFMA GEMVs
+  if (h->wide) h->attn_split = false;  // one workgroup per (head, slot): see forward_layers_wide
   memset(h->host_prompt_len, 0, sizeof(h->host_prompt_len));
   memset(h->host_gen_est, 0, sizeof(h->host_gen_est));
   *out = h;
@@ -485,7 +549,7 @@ static int fold_all(ixtts_gpt* h) {
 static int derive_fused_mlp(ixtts_gpt* h) {
   h->mlp_fused = false;
   static const bool dbg = getenv("IXTTS_DEBUG") != nullptr;
-  if (h->esize != 2 || h->D != MLP_D || h->FF != MLP_FF || h->L < 2) return IXTTS_OK;
+  if (h->esize != 2 || h->D != MLP_D || h->FF != MLP_FF || h->L < 2 || h->wide) return IXTTS_OK;
   const char* m_mlp = getenv("IXTTS_MLP");
   if (!m_mlp || strcmp(m_mlp, "fused")) return IXTTS_OK;
   IX_HIP(hipDeviceSynchronize());  // (a broadcast into the arena may still be in flight on another stream)
@@ -677,7 +741,7 @@ extern "C" int ixtts_gpt_decode(ixtts_gpt* h, int n_active, int n_steps, const i
 // ------------------------------------------------------------------------------------ beam-sample
 extern "C" int ixtts_gpt_beam_begin(ixtts_gpt* h, int num_beams, void* stream) {
   NEED_READY(h, "gpt_beam_begin");
-  IX_ARG(num_beams >= 2 && num_beams <= h->cfg.max_batch && num_beams <= MAXB, "gpt_beam_begin: num_beams %d needs max_batch >= it (<= %d)", num_beams, MAXB);
+  IX_ARG(num_beams >= 2 && num_beams <= h->cfg.max_batch && num_beams <= MAXB_REG, "gpt_beam_begin: num_beams %d needs max_batch >= it (<= %d)", num_beams, MAXB_REG);
   IX_ARG(h->host_prompt_len[0] > 0, "gpt_beam_begin: slot 0 has no prefilled prompt");
   hipStream_t st = (hipStream_t)stream;
   const int D = h->D, V = h->V;
