@@ -294,7 +294,8 @@ def main():
         P, max_codes, max_batch = 34 + max_tok + 2 + 1, 11 * max_tok, slots
     else:
         P, max_codes = 34 + n_tok + 2 + 1, n_codes
-        max_batch = slots if R > 1 else (3 if args.decode == "beam" else min(max(2, n_seg), engine_max))
+        # R requests in flight: one decode slot per segment (wide engines step up to 16 together on the matrix cores)
+        max_batch = min(slots, R * n_seg) if R > 1 else (3 if args.decode == "beam" else min(max(2, n_seg), engine_max))
     frames = int(max_codes * 1.72)
     hp = make_hotpath(args, dev, args.dtype, max_batch, P + max_codes + 64, frames)
 

@@ -263,13 +263,13 @@ static void launch_sampler(ixtts_gpt* h, int n_active, hipStream_t st) {
 
 
 // ------------------------------------------------------------------------------------ wide engines (gpt_wide.h)
-// max_batch > 4: bf16 only.  Rows per workgroup: one workgroup per CU where the matrix allows (N / 256 rows), at most 16 * NT.
-template <int K, int NT, int INP, int EPI, int NW = 4>
+// max_batch > 4: bf16 only.  Rows per workgroup (RP0 + RP1) make one workgroup per CU at model_dim 1280: 15 / 5 / 16 + 4 / 5 / 16 + 16.
+template <int K, int INP, int EPI, int NW, int RP0, int RP1>
 static int launch_wide(const void* wt, const void* xin, const float* bias, void* out, int N, int B, int slot0, int out_stride, ixtts_gpt* h,
                        void* kc, void* vc, const float* ln_w, const float* ln_b, hipStream_t st) {
-  const int rpw = std::max(1, std::min(16 * NT, ceil_div(N, 256)));
-  hipLaunchKernelGGL((gemv_wide_kernel<K, NT, INP, EPI, bf16, NW>), dim3(ceil_div(N, rpw)), dim3(64 * NW), 0, st, reinterpret_cast<const bf16*>(wt), xin, bias, out, N,
-                     rpw, B, slot0, out_stride, h->smax, kc, vc, (const int*)h->cur_len, h->H, ln_w, ln_b);
+  constexpr int NT = RP1 > 0 ? 2 : 1;
+  hipLaunchKernelGGL((gemv_wide_kernel<K, NT, INP, EPI, bf16, NW, RP0, RP1>), dim3(ceil_div(N, RP0 + RP1)), dim3(64 * NW), 0, st,
+                     reinterpret_cast<const bf16*>(wt), xin, bias, out, N, B, slot0, out_stride, h->smax, kc, vc, (const int*)h->cur_len, h->H, ln_w, ln_b);
   return IXTTS_OK;
 }
 
@@ -279,16 +279,16 @@ static int wide_which(ixtts_gpt* h, int which, int l, int B, int slot0, hipStrea
   const size_t lstride = (size_t)h->slots * D * h->smax * sizeof(bf16);
   switch (which) {
     case 0:
-      return launch_wide<D, 1, WIN_LN, EPI_QKV>(A_PTR(o.wqkv), h->h, A_F32(o.bqkv), h->q, 3 * D, B, slot0, D, h, (uint8_t*)h->kc + l * lstride,
+      return launch_wide<D, WIN_LN, EPI_QKV, 4, 15, 0>(A_PTR(o.wqkv), h->h, A_F32(o.bqkv), h->q, 3 * D, B, slot0, D, h, (uint8_t*)h->kc + l * lstride,
                                                  (uint8_t*)h->vc + l * lstride, nullptr, nullptr, st);
     case 1:
-      return launch_wide<D, 1, WIN_PLAIN, EPI_RESID>(A_PTR(o.wo), h->att, A_F32(o.bo), h->h, D, B, slot0, D, h, nullptr, nullptr, nullptr, nullptr, st);
+      return launch_wide<D, WIN_PLAIN, EPI_RESID, 4, 5, 0>(A_PTR(o.wo), h->att, A_F32(o.bo), h->h, D, B, slot0, D, h, nullptr, nullptr, nullptr, nullptr, st);
     case 2:
-      return launch_wide<D, 2, WIN_LN, EPI_GELU>(A_PTR(o.wfc), h->h, A_F32(o.bfc), h->ff, 4 * D, B, slot0, 4 * D, h, nullptr, nullptr, nullptr, nullptr, st);
+      return launch_wide<D, WIN_LN, EPI_GELU, 4, 16, 4>(A_PTR(o.wfc), h->h, A_F32(o.bfc), h->ff, 4 * D, B, slot0, 4 * D, h, nullptr, nullptr, nullptr, nullptr, st);
     case 3:
-      return launch_wide<4 * D, 1, WIN_FF, EPI_RESID, (D == 1280 ? 8 : 4)>(A_PTR(o.wpr), h->ff, A_F32(o.bpr), h->h, D, B, slot0, D, h, nullptr, nullptr, nullptr, nullptr, st);
+      return launch_wide<4 * D, WIN_FF, EPI_RESID, 4, 5, 0>(A_PTR(o.wpr), h->ff, A_F32(o.bpr), h->h, D, B, slot0, D, h, nullptr, nullptr, nullptr, nullptr, st);
     case 4:
-      return launch_wide<D, 2, WIN_LN2, EPI_LOGITS>(A_PTR(h->whead), h->h, A_F32(h->bhead), h->logits, h->V, B, slot0, h->V, h, nullptr, nullptr,
+      return launch_wide<D, WIN_LN2, EPI_LOGITS, 4, 16, 16>(A_PTR(h->whead), h->h, A_F32(h->bhead), h->logits, h->V, B, slot0, h->V, h, nullptr, nullptr,
                                                     A_F32(h->lnf_w), A_F32(h->lnf_b), st);
   }
   set_error("wide_which: %d", which);

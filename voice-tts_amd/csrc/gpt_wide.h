@@ -7,8 +7,8 @@
 // streamed exactly once, 16 bytes per lane, every load of the kernel issued up front (activations -> epilogue operands ->
 // weights, as in gemv_reg_kernel).
 //
-// One workgroup = 4 waves (8 for the K = 4 D matrix, whose 40 + 40 fragments per lane would not fit a wave's registers) = `rpw` consecutive output rows (up to 16 * NT; one workgroup per CU for the production shapes:
-// 15 / 5 / 20 / 5 / 32 rows for QKV / out-proj / FC / MLP-out / head).  The K dimension is dealt to the waves in 32-element
+// One workgroup = 4 waves = RP0 + RP1 consecutive output rows in one or two 16-row MFMA tiles (one workgroup per CU for the production shapes:
+// 15 / 5 / 16 + 4 / 5 / 16 + 16 rows for QKV / out-proj / FC / MLP-out / head).  The K dimension is dealt to the waves in 32-element
 // k-steps, wave w owning steps w, w+4, w+8, ...: lane (c = lane & 15, g = lane >> 4) of wave w supplies
 //   A: W[row0 + 16 t + c][32 s + 8 g .. +8]   (16 bytes straight from the arena; rows beyond the workgroup's range repeat the last one)
 //   B: X[slot c][32 s + 8 g .. +8]            (8 activations of sequence c)
@@ -50,21 +50,40 @@ __device__ __forceinline__ float seq_block_sum(float v, float* red, int wave, in
   return (red[c] + red[WIDE_COLS + c]) + (red[2 * WIDE_COLS + c] + red[3 * WIDE_COLS + c]);
 }
 
-template <int K, int NT, int INP, int EPI, typename KVT, int NW = 4>
+// lane i of each 16-lane row takes the dword of lane i + N of that row (lanes shifted in from beyond the row read 0)
+template <int N>
+__device__ __forceinline__ uint4 row_shl4(const uint4& v) {
+  if constexpr (N == 0) return v;
+  uint4 r;
+  r.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x100 + N, 0xf, 0xf, true);
+  r.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x100 + N, 0xf, 0xf, true);
+  r.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x100 + N, 0xf, 0xf, true);
+  r.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x100 + N, 0xf, 0xf, true);
+  return r;
+}
+
+// RP0 / RP1: output rows the workgroup owns in tile 0 / 1 (rpw = RP0 + RP1 for a two-tile kernel, RP0 alone otherwise).  A tile
+// with few rows would waste most of every 16-row weight load (5 rows x 64 B per wave-instruction instead of 1 KiB), so its
+// loads are PACKED: 16 / RP k-steps per instruction, lane (m, g) fetching row m % RP of k-step pack m / RP, and the fragment of
+// pack p is moved into place with a DPP row shift (4 v_mov_dpp) when its MFMA is issued.
+template <int K, int NT, int INP, int EPI, typename KVT, int NW, int RP0, int RP1>
 __global__ __launch_bounds__(64 * NW) void gemv_wide_kernel(const bf16* __restrict__ wt, const void* __restrict__ xin, const float* __restrict__ bias, void* out,
-                                                        int N, int rpw, int B, int slot0, int out_stride, int smax, void* kcache, void* vcache,
+                                                        int N, int B, int slot0, int out_stride, int smax, void* kcache, void* vcache,
                                                         const int* __restrict__ cur_len, int heads, const float* __restrict__ ln_w,
                                                         const float* __restrict__ ln_b) {
   static_assert(K % (32 * NW) == 0, "K is dealt to the waves in 32-element k-steps");
   static_assert(NW == 4 || INP == WIN_FF, "the in-register staging of fp32 activations is laid out for 4 waves");
   constexpr int NI = K / (32 * NW);  // k-steps per wave = 8-float chunks per staging thread
   constexpr int NPASS = INP == WIN_LN ? 1 : (INP == WIN_LN2 ? 2 : 0);
+  static_assert(RP0 >= 1 && RP0 <= 16 && RP1 >= 0 && RP1 <= 16 && (NT == 2) == (RP1 > 0), "rows per tile");
+  constexpr int KP0 = 16 / RP0, KP1 = RP1 > 0 ? 16 / RP1 : 1;              // k-steps per weight load
+  constexpr int NL0 = (NI + KP0 - 1) / KP0, NL1 = (NI + KP1 - 1) / KP1;      // weight loads per lane
+  constexpr int NLM = NL0 > NL1 ? NL0 : NL1;
   __shared__ float red[4 * NPASS + 1][4 * WIDE_COLS];
   __shared__ __attribute__((aligned(16))) float part[NW][NT][64][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int row0 = blockIdx.x * rpw;
-  const int rows_here = min(rpw, N - row0);
+  const int row0 = blockIdx.x * (RP0 + RP1);
   const int slot_c = slot0 + min(c, B - 1);  // columns beyond the batch repeat the last sequence (finite, never stored)
 
   // ---- 1. activations of this lane: chunk (4 wave + g) + 16 i of sequence c  ==  k-step wave + 4 i, elements 8 g .. 8 g + 7
@@ -98,20 +117,23 @@ __global__ __launch_bounds__(64 * NW) void gemv_wide_kernel(const bf16* __restri
   int pre_pos = 0;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int n = row0 + min(t * 16 + em, rows_here - 1);
+    const int n = min(row0 + (t == 0 ? 0 : RP0) + min(em, (t == 0 ? RP0 : RP1) - 1), N - 1);
     pre_bias[t] = bias[n];
     pre_res[t] = 0.f;
     if constexpr (EPI == EPI_RESID) pre_res[t] = reinterpret_cast<const float*>(out)[(size_t)eslot * out_stride + n];
   }
   if constexpr (EPI == EPI_QKV) pre_pos = cur_len[eslot];
   __builtin_amdgcn_sched_barrier(0);
-  // ---- 3. weight stream: fragment (k-step wave + 4 i, tile t) = 16 rows x 64 bytes, rows beyond the range repeat the last one
-  uint4 a[NI][NT];
+  // ---- 3. weight stream: load j of tile t = k-steps j KP .. j KP + KP - 1 of the rows of that tile (rows / packs beyond the
+  // range repeat a valid address; their products land in accumulator rows nobody reads)
+  uint4 a[NT][NLM];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const bf16* wrow = wt + (size_t)(row0 + min(t * 16 + c, rows_here - 1)) * K + g * 8;
+    const int RP = t == 0 ? RP0 : RP1, KP = t == 0 ? KP0 : KP1, NL = t == 0 ? NL0 : NL1;
+    const int pk = min(c / RP, KP - 1);
+    const bf16* wrow = wt + (size_t)min(row0 + (t == 0 ? 0 : RP0) + c % RP, N - 1) * K + g * 8;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) a[i][t] = *reinterpret_cast<const uint4*>(wrow + (wave + NW * i) * 32);
+    for (int j = 0; j < NL; ++j) a[t][j] = *reinterpret_cast<const uint4*>(wrow + (wave + NW * min(j * KP + pk, NI - 1)) * 32);
   }
   __builtin_amdgcn_sched_barrier(0);
   // ---- 4. LayerNorm of sequence c over its 16 threads (4 lanes in each of the 4 waves), in registers
@@ -156,7 +178,30 @@ __global__ __launch_bounds__(64 * NW) void gemv_wide_kernel(const bf16* __restri
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const wbf16x8 af = __builtin_bit_cast(wbf16x8, a[i][t]);
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int KP = t == 0 ? KP0 : KP1;
+      uint4 raw;
+      // (i, t are compile-time after unrolling: the switch folds to one shift)
+      switch ((i % KP) * (t == 0 ? RP0 : RP1)) {
+        case 0: raw = a[t][i / KP]; break;
+        case 1: raw = row_shl4<1>(a[t][i / KP]); break;
+        case 2: raw = row_shl4<2>(a[t][i / KP]); break;
+        case 3: raw = row_shl4<3>(a[t][i / KP]); break;
+        case 4: raw = row_shl4<4>(a[t][i / KP]); break;
+        case 5: raw = row_shl4<5>(a[t][i / KP]); break;
+        case 6: raw = row_shl4<6>(a[t][i / KP]); break;
+        case 7: raw = row_shl4<7>(a[t][i / KP]); break;
+        case 8: raw = row_shl4<8>(a[t][i / KP]); break;
+        case 9: raw = row_shl4<9>(a[t][i / KP]); break;
+        case 10: raw = row_shl4<10>(a[t][i / KP]); break;
+        case 11: raw = row_shl4<11>(a[t][i / KP]); break;
+        case 12: raw = row_shl4<12>(a[t][i / KP]); break;
+        case 13: raw = row_shl4<13>(a[t][i / KP]); break;
+        case 14: raw = row_shl4<14>(a[t][i / KP]); break;
+        default: raw = row_shl4<15>(a[t][i / KP]); break;
+      }
+      const wbf16x8 af = __builtin_bit_cast(wbf16x8, raw);
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bh, acc[t], 0, 0, 0);
       if constexpr (INP != WIN_FF) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl, acc[t], 0, 0, 0);
     }
@@ -168,12 +213,11 @@ __global__ __launch_bounds__(64 * NW) void gemv_wide_kernel(const bf16* __restri
   const int src_lane = (em >> 2) * 16 + en, src_j = em & 3;  // C/D map: col = lane & 15, row = (lane >> 4) * 4 + j
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int r = t * 16 + em;
-    if (tid < 256 && r < rows_here && en < B) {
+    const int n = row0 + (t == 0 ? 0 : RP0) + em;  // accumulator row em of tile t
+    if (tid < 256 && em < (t == 0 ? RP0 : RP1) && n < N && en < B) {
       float v = (part[0][t][src_lane][src_j] + part[1][t][src_lane][src_j]) + (part[2][t][src_lane][src_j] + part[3][t][src_lane][src_j]);
       if constexpr (NW == 8) v += (part[4][t][src_lane][src_j] + part[5][t][src_lane][src_j]) + (part[6][t][src_lane][src_j] + part[7][t][src_lane][src_j]);
       v += pre_bias[t];
-      const int n = row0 + r;
       if constexpr (EPI == EPI_RESID) {
         reinterpret_cast<float*>(out)[(size_t)eslot * out_stride + n] = pre_res[t] + v;
       } else if constexpr (EPI == EPI_GELU) {
