@@ -6,9 +6,14 @@
 // HBM layout
 //   weight arena (one hipMalloc, broadcastable): per conv  Wq[phase][tap][Cin_pad/8][2][Cout_pad][4] fp32
 //   + bias[Cout]; per activation log_alpha[C], log_beta[C]; the 12 filter taps.
-//   activations: 5 ping-pong buffers of 6144*F*B floats ([B][C][T] row-major, T contiguous):
-//     XS  previous stage output / 3-way resblock accumulator      X   stage input (after ups)
-//     R   running resblock state   T1  activation output   T2  conv1 output
+//   activations: 11 buffers of 6144*F*B floats ([B][C][T] row-major, T contiguous):
+//     XS  previous stage output      X   stage input (after ups)
+//     per resblock branch j (3 of them): R_j running state / branch result, T1_j activation output, T2_j conv1 output
+//
+// The three AMPBlock1 branches of a stage (k = 3, 7, 11) read the same input and only meet in the mean, so they run
+// CONCURRENTLY on three streams (forked after the up-sampling conv, joined in front of the k = 11 branch's last conv,
+// whose epilogue forms ((r0 + r1) + r2) / 3): the conv tiles of one branch fill the CUs another branch's last partial
+// round of tiles leaves idle, and the HBM-bound activation passes run beside MFMA-bound convs.
 #include <map>
 #include <vector>
 
@@ -41,8 +46,12 @@ struct ixtts_bigvgan {
   float* arena = nullptr;
   size_t arena_floats = 0;
   size_t filt_off = 0, zero_off = 0;
-  float* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  static constexpr int NBUF = 11;
+  float* buf[NBUF] = {};
   size_t buf_floats = 0;
+  hipStream_t side[2] = {nullptr, nullptr};  // streams of the k = 3 / k = 7 branches (the caller's stream carries k = 11)
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  bool concurrent = true;                    // IXTTS_BV_STREAMS=1 keeps everything on the caller's stream
   int total_up = 1;
   bool finalized = false;
 };
@@ -89,6 +98,7 @@ extern "C" int ixtts_bigvgan_create(ixtts_bigvgan** out, const ixtts_bigvgan_cfg
   auto* h = new (std::nothrow) ixtts_bigvgan();
   if (!h) return IXTTS_ERR_NOMEM;
   h->cfg = *cfg;
+  if (const char* e = getenv("IXTTS_BV_STREAMS")) h->concurrent = strcmp(e, "1") != 0;
   size_t off = 0;
   h->filt_off = off;
   off += 16;
@@ -157,12 +167,12 @@ static int ensure_workspace(ixtts_bigvgan* h, int B, int F) {
   }
   size_t need = per_frame * (size_t)F * B;
   if (need <= h->buf_floats) return IXTTS_OK;
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < ixtts_bigvgan::NBUF; ++i) {
     if (h->buf[i]) hipFree(h->buf[i]);
     h->buf[i] = nullptr;
   }
   h->buf_floats = 0;
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < ixtts_bigvgan::NBUF; ++i) {
     if (hipMalloc(&h->buf[i], need * sizeof(float)) != hipSuccess) {
       set_error("bigvgan: workspace hipMalloc(%zu) failed", need * sizeof(float));
       return IXTTS_ERR_NOMEM;
@@ -287,7 +297,7 @@ static int run_act(ixtts_bigvgan* h, const std::string& name, const float* x, fl
 }
 
 static int run_conv(ixtts_bigvgan* h, const std::string& name, const float* x, float* y, const float* res,
-                    const float* accum, int div3, int B, int Tin, hipStream_t st) {
+                    const float* accum, int div3, int B, int Tin, hipStream_t st, const float* accum2 = nullptr) {
   const ConvDesc& d = h->convs.at(name);
   ConvParams p;
   memset(&p, 0, sizeof(p));
@@ -297,6 +307,7 @@ static int run_conv(ixtts_bigvgan* h, const std::string& name, const float* x, f
   p.zeros = h->arena + h->zero_off;
   p.res = res;
   p.accum = accum;
+  p.accum2 = accum2;
   p.y = y;
   p.B = B;
   p.Cin = d.Cin;
@@ -364,30 +375,47 @@ extern "C" int ixtts_bigvgan_forward(ixtts_bigvgan* h, const float* mel, int B, 
   if (B == 0 || F == 0) return IXTTS_OK;
   hipStream_t st = (hipStream_t)stream;
   IX_TRY(ensure_workspace(h, B, F));
-  float *XS = h->buf[0], *X = h->buf[1], *R = h->buf[2], *T1 = h->buf[3], *T2 = h->buf[4];
+  float *XS = h->buf[0], *X = h->buf[1];
+  float* T1 = h->buf[3];
   const ixtts_bigvgan_cfg& c = h->cfg;
+  static const bool timing = getenv("IXTTS_BV_TIMING") != nullptr;
+  const bool conc = h->concurrent && !timing;
+  if (conc && !h->ev_fork) {
+    for (int k = 0; k < 2; ++k) {
+      IX_HIP(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+      IX_HIP(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
+    }
+    IX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  }
   IX_TRY(run_conv(h, "conv_pre", mel, XS, nullptr, nullptr, 0, B, F, st));
   int T = F;
   for (int i = 0; i < c.n_stages; ++i) {
     IX_TRY(run_conv(h, "ups." + std::to_string(i) + ".0", XS, X, nullptr, nullptr, 0, B, T, st));
     T *= c.upsample_rates[i];
+    if (conc) IX_HIP(hipEventRecord(h->ev_fork, st));
+    // branch j works in (R_j, T1_j, T2_j); the longest one (the last kernel size) stays on the caller's stream and forms the mean
     for (int j = 0; j < c.n_resblock_kernels; ++j) {
+      const bool last = j == c.n_resblock_kernels - 1;
+      hipStream_t bs = (conc && !last) ? h->side[j] : st;
+      float *Rj = h->buf[2 + 3 * j], *T1j = h->buf[3 + 3 * j], *T2j = h->buf[4 + 3 * j];
+      if (conc && !last) IX_HIP(hipStreamWaitEvent(bs, h->ev_fork, 0));
       std::string p = "resblocks." + std::to_string(i * c.n_resblock_kernels + j);
       const float* cur = X;
       for (int m = 0; m < 3; ++m) {
-        IX_TRY(run_act(h, p + ".activations." + std::to_string(2 * m) + ".act", cur, T1, B, T, st));
-        IX_TRY(run_conv(h, p + ".convs1." + std::to_string(m), T1, T2, nullptr, nullptr, 0, B, T, st));
-        IX_TRY(run_act(h, p + ".activations." + std::to_string(2 * m + 1) + ".act", T2, T1, B, T, st));
-        if (m < 2) {
-          IX_TRY(run_conv(h, p + ".convs2." + std::to_string(m), T1, R, cur, nullptr, 0, B, T, st));
-          cur = R;
+        IX_TRY(run_act(h, p + ".activations." + std::to_string(2 * m) + ".act", cur, T1j, B, T, bs));
+        IX_TRY(run_conv(h, p + ".convs1." + std::to_string(m), T1j, T2j, nullptr, nullptr, 0, B, T, bs));
+        IX_TRY(run_act(h, p + ".activations." + std::to_string(2 * m + 1) + ".act", T2j, T1j, B, T, bs));
+        if (m < 2 || !last) {
+          IX_TRY(run_conv(h, p + ".convs2." + std::to_string(m), T1j, Rj, cur, nullptr, 0, B, T, bs));
+          cur = Rj;
         } else {
           // xs = r0 ; xs += r1 ; x = (xs + r2) / 3      (bigvgan.py:369-375)
-          const float* accum = (j == 0) ? nullptr : XS;
-          int div3 = (j == c.n_resblock_kernels - 1) ? 1 : 0;
-          IX_TRY(run_conv(h, p + ".convs2." + std::to_string(m), T1, XS, cur, accum, div3, B, T, st));
+          if (conc)
+            for (int k = 0; k < 2; ++k) IX_HIP(hipStreamWaitEvent(st, h->ev_join[k], 0));
+          IX_TRY(run_conv(h, p + ".convs2." + std::to_string(m), T1j, XS, cur, h->buf[2], 1, B, T, st, h->buf[5]));
         }
       }
+      if (conc && !last) IX_HIP(hipEventRecord(h->ev_join[j], bs));
     }
   }
   IX_TRY(run_act(h, "activation_post.act", XS, T1, B, T, st));
@@ -415,8 +443,13 @@ extern "C" double ixtts_bigvgan_flops(const ixtts_bigvgan* h, int B, int F) {
 extern "C" int ixtts_bigvgan_destroy(ixtts_bigvgan* h) {
   if (!h) return IXTTS_OK;
   if (h->arena) hipFree(h->arena);
-  for (int i = 0; i < 5; ++i)
+  for (int i = 0; i < ixtts_bigvgan::NBUF; ++i)
     if (h->buf[i]) hipFree(h->buf[i]);
+  for (int k = 0; k < 2; ++k) {
+    if (h->side[k]) hipStreamDestroy(h->side[k]);
+    if (h->ev_join[k]) hipEventDestroy(h->ev_join[k]);
+  }
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
   delete h;
   return IXTTS_OK;
 }

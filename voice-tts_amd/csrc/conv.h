@@ -10,6 +10,7 @@ struct ConvParams {
   const float* bias;   // [Cout] or null
   const float* res;    // [B][Cout][Tout] or null  (residual)
   const float* accum;  // [B][Cout][Tout] or null  (running sum of the stage's resblocks)
+  const float* accum2; // [B][Cout][Tout] or null  (a second resblock result: y = ((accum + accum2) + conv) / 3)
   float* y;            // [B][Cout][Tout]
   const float* zeros;  // >= 16 floats of zeros in device memory: the target of loads that must not happen (absent operand, padding)
   int B, Cin, Cin_pad, Cout, Cout_pad, Tin, Tout;

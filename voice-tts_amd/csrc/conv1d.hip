@@ -201,13 +201,14 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
       const int t = q * p.os + ophase;
       const bool tv = (q < p.Nq) && (t >= 0) && (t < p.Tout);
       const int tc = min(max(t, 0), p.Tout - 1);
-      float rv[16], av[16];
+      float rv[16], av[16], av2[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = min(m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.Cout - 1);
         const size_t o = ob + (size_t)m * p.Tout + tc;
         rv[r] = *(p.res ? p.res + o : p.zeros);
         av[r] = *(p.accum ? p.accum + o : p.zeros);
+        av2[r] = *(p.accum2 ? p.accum2 + o : p.zeros);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
         float v = acc[i][j][r];
         if (p.bias) v += bv[i][r];
         if (p.res) v += rv[r];
-        if (p.accum) v = av[r] + v;
+        if (p.accum2) v = (av[r] + av2[r]) + v;  // xs = r0; xs += r1; xs += r2 (bigvgan.py:369-375): same order
+        else if (p.accum) v = av[r] + v;
         if (p.div3) v = v / 3.0f;
         if (tv && m < p.Cout) p.y[ob + (size_t)m * p.Tout + t] = v;
       }
