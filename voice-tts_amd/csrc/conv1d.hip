@@ -27,14 +27,16 @@ namespace ixtts {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int CG = 8;   // input channels per weight group (one float4 per lane = 4 MFMA k-steps)
-constexpr int CKG = 4;  // groups per K-chunk: the x tile in LDS covers 32 input channels
+// CKG groups per K-chunk (template parameter): the x tile in LDS covers 8 CKG input channels -- 32, or 24 for the 24- / 48-channel
+// stages, whose last 32-channel chunk would run a quarter of its MFMAs on zeroed weights
 
 // Weights are packed Wq[phase][tap][ci/8][ci%2][co][(ci%8)/2]: lane (co = l31, k-parity = lh) reads ONE float4
 // holding its A operand for the 4 consecutive k-steps of a channel group; a half-wave reads 512 contiguous bytes.
 // They stream from L2 (the XCD-aware tile map keeps one co-slice per XCD) straight into registers, one tap ahead;
 // only the x tile (+dilation halo) lives in LDS.
-template <int MT, int NT, int WM, int WN>
+template <int MT, int NT, int WM, int WN, int CKG = 4>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
+  static_assert(CKG == 3 || CKG == 4, "three or four 8-channel groups per chunk");
   constexpr int BM = 32 * MT * WM;
   constexpr int BN = 32 * NT * WN;
   static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
   auto issue_dma = [&](int g, float* __restrict__ dst) {
     const int c0 = min(g, nchunks - 1) * (CKG * CG) + wave * 8;
     float* dst0 = dst + (wave * 8) * XWP;
+    if (CKG < 4 && wave >= CKG) return;  // a 24-row chunk is copied by three of the four waves
     for (int pc = 0; pc < np; ++pc) {
       const int cs = (pc < np - 1) ? pc * 64 : XW - 64;
       const int t = lo + cs + lane;
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
   }
 }
 
-template <int MT, int NT, int WM, int WN>
+template <int MT, int NT, int WM, int WN, int CKG = 4>
 static int launch_cfg(const ConvParams& p0, hipStream_t st) {
   ConvParams p = p0;
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
@@ -237,7 +240,7 @@ static int launch_cfg(const ConvParams& p0, hipStream_t st) {
   size_t smem = (size_t)(2 * CKG * CG * XWP) * sizeof(float);  // two x-tile buffers
   IX_ARG(smem <= 160 * 1024, "conv: LDS tile %zu B too large", smem);
   IX_ARG(BN + (p.ntap - 1) * adil <= 512, "conv: x tile of %d columns exceeds the staging bound (512)", BN + (p.ntap - 1) * adil);
-  auto kern = conv1d_mfma_kernel<MT, NT, WM, WN>;
+  auto kern = conv1d_mfma_kernel<MT, NT, WM, WN, CKG>;
   if (smem > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -270,9 +273,10 @@ static double tile_score(const ConvParams& p, int BM, int BN, double pref) {
 
 int launch_conv1d(const ConvParams& p, hipStream_t st) {
   IX_ARG(p.Cin_pad % CG == 0, "conv: Cin_pad %d not a multiple of %d", p.Cin_pad, CG);
+  const bool k24 = p.Cin_pad % 24 == 0 && p.Cin_pad % 32 != 0;  // 24 / 48 input channels: 24-channel chunks, no dead group
   switch (conv_tile_bm(p.Cout)) {
-    case 32: return launch_cfg<1, 2, 1, 4>(p, st);   // 32 x 256
-    case 64: return launch_cfg<2, 1, 1, 4>(p, st);   // 64 x 128
+    case 32: return k24 ? launch_cfg<1, 2, 1, 4, 3>(p, st) : launch_cfg<1, 2, 1, 4>(p, st);   // 32 x 256
+    case 64: return k24 ? launch_cfg<2, 1, 1, 4, 3>(p, st) : launch_cfg<2, 1, 1, 4>(p, st);   // 64 x 128
     case 96: return launch_cfg<3, 1, 1, 4>(p, st);   // 96 x 128
     default: {
       const double s128 = tile_score(p, 128, 128, 1.00), s64x128 = tile_score(p, 64, 128, 0.96), s64 = tile_score(p, 64, 64, 0.90);
