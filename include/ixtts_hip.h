@@ -163,14 +163,16 @@ typedef struct ixtts_gpt_cfg {
 typedef struct ixtts_sampler_cfg {
   float repetition_penalty; /* 10.0 (infer_v2.py:605); 1.0 disables                         */
   float temperature;        /* 0.8; ignored when do_sample == 0                              */
-  int top_k;                /* 30 (1..128 on the device); "greedy" of BASELINE configs == do_sample 0 or top_k 1 */
+  int top_k;                /* 30; 0 (or >= vocabulary) disables the filter; any value for sampling, 1..128 in beam mode;
+                               "greedy" of BASELINE configs == do_sample 0 or top_k 1 */
   float top_p;              /* 0.8                                                           */
   int do_sample;            /* 0: argmax of penalised logits; 1: multinomial after warpers   */
   int suppress_stop;        /* bench-only fixed-length mode: stop token forced to -inf       */
   uint64_t seed;            /* Philox seed for do_sample (cannot match torch's CPU stream)   */
   float typical_mass;       /* > 0: the custom TypicalLogitsWarper of `inference_speech(typical_sampling=True, typical_mass=...)`
                                (model_v2.py:717-722, utils/typical_sampling.py) after the repetition penalty; 0: off */
-  int reserved;
+  float length_penalty;     /* beam mode: hypothesis score = sum_logprobs / generated_len ** length_penalty
+                               (transformers_beam_search.py:947-951,989-1006); 0.0 is the served default (infer_v2.py:603) */
 } ixtts_sampler_cfg;
 
 typedef struct ixtts_gpt ixtts_gpt;

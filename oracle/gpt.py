@@ -378,7 +378,7 @@ def beam_scores_step(logits_rows, histories_full, beam_scores, theta, temperatur
 
 
 def generate_beam_sample(oracle, embeds, mask, max_new, num_beams=3, theta=10.0, temperature=0.8, top_k=30, top_p=0.8,
-                         stop_mel=8193, start_mel=8192, sampler=None, generator=None, trace=None):
+                         stop_mel=8193, start_mel=8192, sampler=None, generator=None, trace=None, length_penalty=0.0):
     """`_beam_search` with do_sample=True (generation_utils.py:3406-3565): the served default.
 
     `sampler(scores_flat[num_beams*V]) -> 2*num_beams flat indices` lets a test force the draws;
@@ -392,7 +392,7 @@ def generate_beam_sample(oracle, embeds, mask, max_new, num_beams=3, theta=10.0,
     pasts = [past0 for _ in range(num_beams)]
     hist = [[] for _ in range(num_beams)]
     beam_scores = [0.0] + [-1e9] * (num_beams - 1)
-    hyps, done = BeamHyps(num_beams), False
+    hyps, done = BeamHyps(num_beams, length_penalty), False
     for step in range(1, max_new + 1):
         scores = beam_scores_step(logits, [prefix + h for h in hist], beam_scores, theta, temperature, top_k, top_p)
         flat = scores.reshape(-1)

@@ -200,14 +200,15 @@ def gen_gpt_block_prod():
 
 def gen_beam():
     out = {}
-    for tag, bias, seed in (("noeos", 14.0, 61), ("mid", 31.0, 64), ("mid2", 34.0, 65), ("eos", 38.0, 62), ("eos2", 42.0, 63)):
-        r = _gen_beam_case(bias, seed)
+    for tag, bias, seed, lp in (("noeos", 14.0, 61, 0.0), ("mid", 31.0, 64, 0.0), ("mid2", 34.0, 65, 0.0), ("eos", 38.0, 62, 0.0), ("eos2", 42.0, 63, 0.0),
+                                ("lp1", 36.0, 66, 1.0), ("lpneg", 34.0, 67, -0.7), ("lp2noeos", 14.0, 68, 2.0)):
+        r = _gen_beam_case(bias, seed, lp)
         print(tag, "steps", r["picks"].shape[0], "done", int(r["done"]), "seq", r["sequence"].tolist())
         out.update({f"{tag}_{k}": v for k, v in r.items()})
     save("gpt_beam.npz", seed=31, **out)
 
 
-def _gen_beam_case(stop_bias, rng_seed):
+def _gen_beam_case(stop_bias, rng_seed, length_penalty=0.0):
     """3-beam beam-sample through the reference's own BeamSearchScorer (vendored text,
     transformers_beam_search.py:123-417) + HF processors + the reference model forward; draws come from a
     seeded torch.multinomial and are stored so any implementation can replay them."""
@@ -232,7 +233,7 @@ def _gen_beam_case(stop_bias, rng_seed):
     model.store_mel_emb(embeds)
     procs = [RepetitionPenaltyLogitsProcessor(10.0), TemperatureLogitsWarper(0.8), TopKLogitsWarper(30, min_tokens_to_keep=2),
              TopPLogitsWarper(0.8, min_tokens_to_keep=2)]
-    scorer = BeamSearchScorer(batch_size=1, num_beams=nb, device="cpu", length_penalty=0.0, do_early_stopping=False,
+    scorer = BeamSearchScorer(batch_size=1, num_beams=nb, device="cpu", length_penalty=length_penalty, do_early_stopping=False,
                               num_beam_hyps_to_keep=1, max_length=P + max_new)
     input_ids = input_ids.repeat_interleave(nb, dim=0)
     mask = mask.repeat_interleave(nb, dim=0)
@@ -274,7 +275,7 @@ def _gen_beam_case(stop_bias, rng_seed):
     fin = scorer.finalize(input_ids, beam_scores, next_tokens, next_indices, pad_token_id=8193, eos_token_id=8193,
                           max_length=P + max_new, decoder_prompt_len=P)
     seq = fin["sequences"][0, P:]
-    return dict(stop_bias=stop_bias, conds_latent=conds_latent, text=text, max_new=max_new, picks=torch.stack(all_picks),
+    return dict(stop_bias=stop_bias, length_penalty=length_penalty, conds_latent=conds_latent, text=text, max_new=max_new, picks=torch.stack(all_picks),
                 next_scores=torch.stack(all_ns), next_tokens=torch.stack(all_nt), next_indices=torch.stack(all_ni),
                 sequence=seq, sequence_score=fin["sequence_scores"], done=int(bool(scorer.is_done)))
 
@@ -544,6 +545,15 @@ def gen_sampler():
             tag = f"{case}_typ{int(mass * 100)}"
             out[tag + "_kept"] = torch.isfinite(t1[0])
             out[tag + "_probs"] = torch.softmax(t4[0], -1)
+        # G8 corners generate() can reach through infer(top_k=..., top_p=...): top_k beyond 128, top_k = 0 (HF then builds no
+        # TopK warper, generation_utils.py:1035-1038), top_p = 1.0 (no TopP warper), a top_p so small only the best survives
+        for wk, wp, wt in ((0, 0.8, 0.8), (500, 0.95, 0.9), (129, 0.6, 0.8), (0, 1.0, 1.3), (0, 0.02, 0.8), (4000, 0.999, 1.0)):
+            w = TemperatureLogitsWarper(wt)(hist, s1.clone()) if wt != 1.0 else s1.clone()
+            if wk > 0:
+                w = TopKLogitsWarper(wk, min_tokens_to_keep=min_keep)(hist, w)
+            if wp < 1.0:
+                w = TopPLogitsWarper(wp, min_tokens_to_keep=min_keep)(hist, w)
+            out[f"{case}_wide_k{wk}_p{int(wp * 1000)}_t{int(wt * 10)}"] = torch.softmax(w[0], -1)
     save("sampler_kat.npz", **out)
 
 

@@ -304,7 +304,7 @@ def beam_engines(golden, dev):
     g = golden("gpt_beam.npz")
     cfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2)
     out = {}
-    for tag in ("noeos", "mid", "mid2", "eos", "eos2"):
+    for tag in ("noeos", "mid", "mid2", "eos", "eos2", "lp1", "lpneg", "lp2noeos"):
         W = WR.make_gpt_weights(cfg, seed=int(g["seed"]), head_scale=50.0)
         W["mel_head.bias"] = W["mel_head.bias"].clone()
         W["mel_head.bias"][8193] += float(g[f"{tag}_stop_bias"])
@@ -314,7 +314,7 @@ def beam_engines(golden, dev):
     return g, out
 
 
-@pytest.mark.parametrize("tag", ["noeos", "mid", "mid2", "eos", "eos2"])
+@pytest.mark.parametrize("tag", ["noeos", "mid", "mid2", "eos", "eos2", "lp1", "lpneg", "lp2noeos"])
 def test_beam_sample_replays_reference_trace(beam_engines, tag):
     """Served default (num_beams=3, do_sample): device processors + BeamSearchScorer bookkeeping + KV reorder,
     replaying the draws recorded from the reference's own scorer run (tests/golden/gpt_beam.npz)."""
@@ -323,11 +323,12 @@ def test_beam_sample_replays_reference_trace(beam_engines, tag):
     fake, embeds, mask = orc.prepare_gpt_inputs(torch.from_numpy(g[f"{tag}_conds_latent"]), g[f"{tag}_text"])
     picks = g[f"{tag}_picks"]
     max_new = int(g[f"{tag}_max_new"])
+    lp = float(g[f"{tag}_length_penalty"]) if f"{tag}_length_penalty" in g.files else 0.0  # lp1 / lpneg / lp2noeos: 1.0 / -0.7 / 2.0
     eng.prefill(0, embeds, 0)
     eng.beam_begin(3)
     for step in range(picks.shape[0]):
         eng.beam_force(picks[step])
-        eng.beam_decode(1, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8)
+        eng.beam_decode(1, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, length_penalty=lp)
         ids, done, score, bs, lt, src = eng.beam_read(max_new)
         assert lt.tolist() == g[f"{tag}_next_tokens"][step].tolist(), step
         assert src.tolist() == g[f"{tag}_next_indices"][step].tolist(), step
@@ -337,7 +338,7 @@ def test_beam_sample_replays_reference_trace(beam_engines, tag):
     assert abs(score - float(g[f"{tag}_sequence_score"][0])) <= 2e-3 * max(1.0, abs(score))
     # once done, further steps change nothing (HF leaves the loop)
     if done:
-        eng.beam_decode(3, repetition_penalty=10.0)
+        eng.beam_decode(3, repetition_penalty=10.0, length_penalty=lp)
         ids2, done2 = eng.beam_read(max_new)[:2]
         assert done2 and ids2.tolist() == ids.tolist()
 

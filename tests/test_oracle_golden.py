@@ -127,6 +127,24 @@ def test_gpt_production_width_layer_vs_reference(golden):
 
 
 @pytest.mark.parametrize("case,min_keep", [("sample", 1), ("beam", 2)])
+def test_sampler_corner_settings_vs_hf(golden, case, min_keep):
+    """top_k = 0 (no TopK warper), top_k beyond 128, top_p = 1.0 (no TopP warper), a top_p that leaves min_tokens_to_keep: the
+    probability vector the HF warpers produce for each setting (tests/golden/sampler_kat.npz, `*_wide_*`)."""
+    g = golden("sampler_kat.npz")
+    s_in = torch.from_numpy(g[f"{case}_in"])
+    hist = g[f"{case}_hist"].tolist()
+    keys = [k for k in g.files if k.startswith(f"{case}_wide_")]
+    assert len(keys) == 6
+    for key in keys:
+        k, p, t = (int(x[1:]) for x in key.split("_")[2:])
+        fin = OG.process_logits(s_in, hist, 10.0, t / 10.0, k, p / 1000.0, min_keep)
+        ref = torch.from_numpy(g[key])
+        got = torch.softmax(fin, -1)
+        assert torch.equal(got > 0, ref > 0), key
+        assert torch.allclose(got, ref, atol=1e-6), key
+
+
+@pytest.mark.parametrize("case,min_keep", [("sample", 1), ("beam", 2)])
 def test_sampler_processors_vs_hf(golden, case, min_keep):
     g = golden("sampler_kat.npz")
     s_in = torch.from_numpy(g[f"{case}_in"])
@@ -157,7 +175,10 @@ def test_typical_sampling_vs_reference_processor(golden, case, min_keep, mass):
     assert torch.allclose(torch.softmax(fin, -1), torch.from_numpy(g[tag + "_probs"]), atol=1e-6)
 
 
-@pytest.mark.parametrize("tag", ["noeos", "mid", "mid2", "eos", "eos2"])
+BEAM_TAGS = ["noeos", "mid", "mid2", "eos", "eos2", "lp1", "lpneg", "lp2noeos"]  # the last three: length_penalty 1.0 / -0.7 / 2.0
+
+
+@pytest.mark.parametrize("tag", BEAM_TAGS)
 def test_beam_sample_vs_reference_scorer(golden, tag):
     """3-beam beam-sample (the served default): oracle loop + scorer restatement vs a trace produced by
     the reference's own BeamSearchScorer / HF processors / model forward, replaying the recorded draws."""
@@ -171,7 +192,8 @@ def test_beam_sample_vs_reference_scorer(golden, tag):
     picks = g[f"{tag}_picks"]
     trace = []
     seq, score = OG.generate_beam_sample(orc, embeds, mask, int(g[f"{tag}_max_new"]), num_beams=3,
-                                         sampler=lambda flat, step: picks[step - 1], trace=trace)
+                                         sampler=lambda flat, step: picks[step - 1], trace=trace,
+                                         length_penalty=float(g[f"{tag}_length_penalty"]) if f"{tag}_length_penalty" in g.files else 0.0)
     assert len(trace) == picks.shape[0]
     for t, ns, nt, ni in zip(trace, g[f"{tag}_next_scores"], g[f"{tag}_next_tokens"], g[f"{tag}_next_indices"]):
         assert t["next_tokens"] == nt.tolist() and t["next_indices"] == ni.tolist()

@@ -35,7 +35,7 @@ class SamplerCfg(C.Structure):
     _fields_ = [
         ("repetition_penalty", C.c_float), ("temperature", C.c_float), ("top_k", C.c_int),
         ("top_p", C.c_float), ("do_sample", C.c_int), ("suppress_stop", C.c_int), ("seed", C.c_uint64),
-        ("typical_mass", C.c_float), ("reserved", C.c_int),
+        ("typical_mass", C.c_float), ("length_penalty", C.c_float),
     ]
 
 

@@ -4,7 +4,7 @@
 //   indextts/gpt/transformers_generation_utils.py:3473-3543  log_softmax -> processors (min_tokens_to_keep = 2)
 //        -> + beam score -> joint softmax over num_beams*V -> multinomial(2*num_beams) w/o replacement -> sort
 //   indextts/gpt/transformers_beam_search.py:215-318          BeamSearchScorer.process
-//   indextts/gpt/transformers_beam_search.py:930-1013         BeamHypotheses.add / is_done (length_penalty 0, early_stopping False)
+//   indextts/gpt/transformers_beam_search.py:930-1013         BeamHypotheses.add / is_done (any length_penalty, early_stopping False)
 //   indextts/gpt/model_v2.py:199-212                          _reorder_cache (index_select of every K/V)
 // `finalize` (transformers_beam_search.py:320-417) runs on the host in ixtts_gpt_beam_read.
 //
@@ -255,16 +255,19 @@ __global__ __launch_bounds__(1024) void beam_step_kernel(BeamArgs a) {
     *a.forced_flag = 0;
     int filled = 0;
     const int gen_len = kstep;  // cur_len - decoder_prompt_len
+    const float lp = cfg.length_penalty;
     float best = -INFINITY;
     for (int r = 0; r < n_pick; ++r) best = fmaxf(best, pick_score[pick_sorted[r]]);
     for (int r = 0; r < n_pick && filled < NB; ++r) {
       const int pi = pick_sorted[r];
       const int flat = pick_flat[pi];
       const int bi = flat / V, tok = flat - bi * V;
-      const float sc = pick_score[pi];
+      const float raw_sc = pick_score[pi];
+      float sc = raw_sc;
       if (tok == s.stop) {
         if (r >= NB) continue;
-        // BeamHypotheses.add(input_ids[beam].clone(), sum_logprobs = sc, generated_len): score = sc / len**0
+        // BeamHypotheses.add(input_ids[beam].clone(), sum_logprobs, generated_len): score = sum_logprobs / generated_len ** length_penalty
+        if (lp != 0.f) sc = raw_sc / powf((float)gen_len, lp);
         int nh = *a.n_hyp;
         if (nh < NB || sc > *a.worst) {
           int dst = nh;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(1024) void beam_step_kernel(BeamArgs a) {
     }
     // is_done(best_sum_logprobs = max of the draws): enough hypotheses and none attainable is better than the worst
     bool d = false;
-    if (*a.n_hyp >= NB) d = (*a.worst >= best);
+    if (*a.n_hyp >= NB) d = (*a.worst >= (lp != 0.f ? best / powf((float)gen_len, lp) : best));
     if (d) {
       *a.done = 1;
       act = 2;

@@ -713,7 +713,6 @@ extern "C" int ixtts_gpt_decode(ixtts_gpt* h, int n_active, int n_steps, const i
   IX_ARG(n_active >= 1 && n_active <= h->cfg.max_batch, "gpt_decode: n_active %d", n_active);
   IX_ARG(n_steps >= 0, "gpt_decode: n_steps %d", n_steps);
   if (sc->do_sample) {
-    IX_ARG(sc->top_k >= 1 && sc->top_k <= SAMP_MAXK, "gpt_decode: do_sample needs 1 <= top_k <= %d (got %d)", SAMP_MAXK, sc->top_k);
     IX_ARG(sc->temperature > 0.f && sc->top_p > 0.f, "gpt_decode: temperature and top_p must be positive");
   }
   IX_ARG(h->V <= 1024 * SAMP_PT, "gpt_decode: vocabulary %d exceeds the sampler tile", h->V);
@@ -856,9 +855,11 @@ extern "C" int ixtts_gpt_beam_read(ixtts_gpt* h, int max_new, int32_t* ids, int 
   for (int i = 0; i < nh; ++i) beams.emplace_back(hs[i], hyp[i]);
   float worst = 1e9f;
   for (auto& bsc : beams) worst = std::min(worst, bsc.first);
+  const float lp = h->samp_host.length_penalty;  // of the last beam_decode call
   if (!dn) {
     for (int b = 0; b < nb; ++b) {
-      const float sc = bs[b];
+      // finalize: beam_hyp.add(final_tokens, final_score, generated_len = tokens generated)  (transformers_beam_search.py:360-371)
+      const float sc = (lp != 0.f && gc > 0) ? bs[b] / powf((float)gc, lp) : bs[b];
       if ((int)beams.size() < nb || sc > worst) {
         beams.emplace_back(sc, open[b]);
         if ((int)beams.size() > nb) {

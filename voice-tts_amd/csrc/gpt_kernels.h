@@ -1485,7 +1485,146 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerState s) {
     tok_s = besti;
   }
 
-  if (sampling) {
+  const bool general = sampling && (cfg.top_k <= 0 || cfg.top_k > SAMP_MAXK);
+  if (general) {
+    // ---- top_k = 0 ("off": HF builds no TopK warper), top_k > 128 or >= V: no survivor list -- the filters become thresholds on
+    // the whole vocabulary and the draw an inverse CDF over it.  TopK: the k-th largest key by the same 4-pass radix select.
+    __shared__ TypicalScratch gs;
+    __shared__ int pick_s;
+    if (cfg.top_k > 0 && cfg.top_k < s.V) {
+      if (threadIdx.x == 0) {
+        sel_prefix = 0u;
+        sel_remaining = (unsigned int)cfg.top_k;
+      }
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+        __syncthreads();
+        const unsigned int prefix = sel_prefix;
+        const unsigned int pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+#pragma unroll
+        for (int i = 0; i < SAMP_PT; ++i) {
+          const int v = threadIdx.x + i * 1024;
+          const unsigned int key = f2key(vals[i]);
+          hist_add_aggregated(hist, (key >> shift) & 0xffu, v < s.V && (key & pmask) == prefix);
+        }
+        __syncthreads();
+        radix_pick_bin(hist, wtot, &sel_prefix, &sel_remaining, shift);
+      }
+      const unsigned int thr = sel_prefix;
+#pragma unroll
+      for (int i = 0; i < SAMP_PT; ++i)
+        if (f2key(vals[i]) < thr) vals[i] = -INFINITY;
+    }
+    // softmax numerators over what is left
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SAMP_PT; ++i) mx = fmaxf(mx, vals[i]);
+    mx = block_max_1024(mx, gs.red);
+    float e[SAMP_PT], se = 0.f;
+#pragma unroll
+    for (int i = 0; i < SAMP_PT; ++i) {
+      e[i] = (vals[i] > -INFINITY) ? expf(vals[i] - mx) : 0.f;
+      se += e[i];
+    }
+    const float Z = block_sum_1024(se, gs.red);
+    if (cfg.top_p < 1.0f) {
+      // ---- TopP: in ascending order of score, tokens go while the running probability mass stays <= 1 - top_p; the largest
+      // always stays (min_tokens_to_keep = 1).  The first key whose inclusive mass exceeds the budget, by a 4-pass radix
+      // select with per-bin MASS histograms in 2^-48 fixed point (integer atomics: independent of their order); tokens
+      // that tie with it are kept.
+      unsigned int key[SAMP_PT];
+      unsigned long long pm[SAMP_PT];
+#pragma unroll
+      for (int i = 0; i < SAMP_PT; ++i) {
+        key[i] = f2key(vals[i]);
+        pm[i] = (unsigned long long)((e[i] / Z) * 281474976710656.0f);
+      }
+      if (threadIdx.x == 0) {
+        gs.prefix = 0u;
+        gs.rem = (unsigned long long)((double)(1.0f - cfg.top_p) * 281474976710656.0);
+      }
+      const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (t < 256) gs.mhist[t] = 0ull;
+        __syncthreads();
+        const unsigned int prefix = gs.prefix;
+        const unsigned long long rem = gs.rem;
+        const unsigned int pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+#pragma unroll
+        for (int i = 0; i < SAMP_PT; ++i)
+          if (t + i * 1024 < s.V && pm[i] > 0ull && (key[i] & pmask) == prefix) atomicAdd(&gs.mhist[(key[i] >> shift) & 0xffu], pm[i]);
+        __syncthreads();
+        unsigned long long x = t < 256 ? gs.mhist[t] : 0ull, pre = x;  // inclusive prefix sums over the bins, ascending
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned int lo = __shfl_up((unsigned int)pre, o, 64), hi = __shfl_up((unsigned int)(pre >> 32), o, 64);
+          if (lane >= o) pre += ((unsigned long long)hi << 32) | lo;
+        }
+        if (t < 256 && lane == 63) gs.wtot[w] = pre;
+        __syncthreads();
+        if (t < 256) {
+          unsigned long long below = 0ull;
+          for (int ww = 0; ww < w; ++ww) below += gs.wtot[ww];
+          const unsigned long long P = pre + below, Pprev = P - x;
+          // the bin in which the running mass first EXCEEDS the budget (no such bin: the top one, where the maximum sits)
+          if ((Pprev <= rem && P > rem) || (t == 255 && P <= rem)) {
+            gs.prefix = prefix | ((unsigned int)t << shift);
+            gs.rem = rem - Pprev;
+          }
+        }
+        __syncthreads();
+      }
+      const unsigned int tau = gs.prefix, kmax = f2key(mx);
+#pragma unroll
+      for (int i = 0; i < SAMP_PT; ++i)
+        if (key[i] < tau && key[i] != kmax) e[i] = 0.f;
+    }
+    // ---- multinomial(1): inverse CDF over the kept tokens in (thread, register) order -- a fixed order, so a fixed stream
+    float mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < SAMP_PT; ++i) mine += e[i];
+    float inc = mine;  // inclusive scan over the wave, then over the 16 waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float y = __shfl_up(inc, o, 64);
+      if ((int)(threadIdx.x & 63) >= o) inc += y;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) gs.red[threadIdx.x >> 6] = inc;
+    if (threadIdx.x == 0) pick_s = -1;
+    __syncthreads();
+    float before = 0.f, total = 0.f;
+    for (int w = 0; w < 16; ++w) {
+      if (w < (int)(threadIdx.x >> 6)) before += gs.red[w];
+      total += gs.red[w];
+    }
+    const float excl = before + inc - mine;
+    const float target = uniform01(cfg.seed, (unsigned int)slot, (unsigned int)st_gen) * total;
+    if (mine > 0.f && target >= excl && target < excl + mine) {  // at most one thread owns the target
+      float c = excl;
+      int pk = -1;
+#pragma unroll
+      for (int i = 0; i < SAMP_PT; ++i) {
+        c += e[i];
+        if (pk < 0 && e[i] > 0.f && target < c) pk = threadIdx.x + i * 1024;
+      }
+      if (pk < 0)
+#pragma unroll
+        for (int i = 0; i < SAMP_PT; ++i)
+          if (e[i] > 0.f) pk = threadIdx.x + i * 1024;  // rounding at the thread's upper edge: its last kept token
+      pick_s = pk;
+    }
+    if (s.probs_out) {
+      float* po = s.probs_out + (size_t)slot * s.V;
+#pragma unroll
+      for (int i = 0; i < SAMP_PT; ++i)
+        if ((int)threadIdx.x + i * 1024 < s.V) po[threadIdx.x + i * 1024] = e[i] / total;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && pick_s >= 0) tok_s = pick_s;  // (target == total by rounding: the argmax already in tok_s)
+  } else if (sampling) {
     // ---- TopK: exact k-th largest key by 4-pass MSB radix select
     const int k = min(max(cfg.top_k, 1), SAMP_MAXK);
     if (threadIdx.x == 0) {

@@ -510,7 +510,9 @@ __global__ __launch_bounds__(256) void attn_rows_flash_kernel(AttnRowsArgs a) {
     __syncthreads();
     {  // stage 64 keys x 64 dims of K and V, widened to fp32: each thread one quarter row of each
       const int key = threadIdx.x >> 2, c16 = (threadIdx.x & 3) * 16;
-      const int t = min(t0 + key, last_key);  // rows past the pass repeat its last one (finite; masked below)
+      // rows past the pass repeat its last one, rows before valid_from (left padding: never written, the cache holds whatever the
+      // allocation held -- 0 x NaN in the P V product would poison the row) repeat the first valid one; both are masked below
+      const int t = min(max(t0 + key, a.valid_from), last_key);
       float kv[16], vv[16];
       load_row16<KVT>(kb + (size_t)t * HD + c16, kv);
       load_row16<KVT>(vb + (size_t)t * HD + c16, vv);

@@ -87,7 +87,7 @@ class GptEngine:
 
     def decode(self, n_active, n_steps, repetition_penalty=10.0, temperature=1.0, top_k=0, top_p=1.0,
                do_sample=False, suppress_stop=False, seed=0, typical_mass=0.0):
-        sc = _lib.SamplerCfg(repetition_penalty, temperature, top_k, top_p, int(do_sample), int(suppress_stop), seed, float(typical_mass), 0)
+        sc = _lib.SamplerCfg(repetition_penalty, temperature, top_k, top_p, int(do_sample), int(suppress_stop), seed, float(typical_mass), 0.0)
         with torch.cuda.device(self.device):
             rc = _lib.lib().ixtts_gpt_decode(self._h, n_active, n_steps, C.byref(sc), self._stream())
         _lib.check(rc, "ixtts_gpt_decode")
@@ -122,8 +122,10 @@ class GptEngine:
             _lib.check(_lib.lib().ixtts_gpt_beam_begin(self._h, int(num_beams), self._stream()), "ixtts_gpt_beam_begin")
         self._nb = int(num_beams)
 
-    def beam_decode(self, n_steps, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=False, seed=0, typical_mass=0.0):
-        sc = _lib.SamplerCfg(repetition_penalty, temperature, top_k, top_p, 1, int(suppress_stop), seed, float(typical_mass), 0)
+    def beam_decode(self, n_steps, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=False, seed=0, typical_mass=0.0,
+                    length_penalty=0.0):
+        sc = _lib.SamplerCfg(repetition_penalty, temperature, top_k, top_p, 1, int(suppress_stop), seed, float(typical_mass), float(length_penalty))
+        self._lp = float(length_penalty)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().ixtts_gpt_beam_decode(self._h, n_steps, C.byref(sc), self._stream()), "ixtts_gpt_beam_decode")
 
@@ -179,8 +181,8 @@ class GptEngine:
         """
         if self.cached_mel_emb is None:
             raise RuntimeError("generate(): call store_mel_emb first (model_v2.py:137)")
-        if num_beams != 1 and (num_beams > self.max_batch or not do_sample or length_penalty != 0.0):
-            raise NotImplementedError("beam mode needs max_batch >= num_beams, do_sample=True and length_penalty=0.0 (the served configuration)")
+        if num_beams != 1 and (num_beams > min(self.max_batch, 4) or not do_sample):
+            raise NotImplementedError("beam mode needs 2 <= num_beams <= min(max_batch, 4) and do_sample=True (beam-sample, the served configuration)")
         # the one custom processor inference_speech ever builds is TypicalLogitsWarper(mass=typical_mass) (model_v2.py:717-722):
         # it runs on the device; anything else has no kernel
         typical_mass = float(unused.pop("typical_mass", 0.0)) if unused.pop("typical_sampling", False) else 0.0
@@ -192,8 +194,9 @@ class GptEngine:
         if inputs.shape[0] != 1 or num_return_sequences != 1:
             raise NotImplementedError("one sequence per generate() call (autoregressive_batch_size = 1, infer_v2.py:602)")
         greedy = (not do_sample) or top_k == 1
-        if not greedy and not (1 <= top_k <= 128):
-            raise NotImplementedError("device sampler supports 1 <= top_k <= 128 (top_k=0 'disabled' is not implemented)")
+        if num_beams != 1 and not (1 <= top_k <= 128):
+            raise NotImplementedError("beam-sample keeps at most 128 candidates per beam on the device: 1 <= top_k <= 128 (sampling without beams takes any top_k, 0 = off)")
+        top_k = max(0, int(top_k))
         P = inputs.shape[1]
         emb = self.cached_mel_emb
         emb = emb[0] if emb.dim() == 3 else emb
@@ -214,7 +217,7 @@ class GptEngine:
             while done_steps < max_new and not fin:
                 n = min(sync_every, max_new - done_steps)
                 self.beam_decode(n, repetition_penalty=repetition_penalty, temperature=temperature, top_k=top_k, top_p=top_p,
-                                 suppress_stop=suppress_stop, seed=int(unused.get("seed", 0)), typical_mass=typical_mass)
+                                 suppress_stop=suppress_stop, seed=int(unused.get("seed", 0)), typical_mass=typical_mass, length_penalty=length_penalty)
                 done_steps += n
                 ids, fin = self.beam_read(max_new)[:2]
             out = torch.cat([inputs.reshape(1, -1).to(torch.long).cpu(), torch.from_numpy(ids.astype(np.int64)).reshape(1, -1)], dim=1)
