@@ -172,6 +172,55 @@ def test_sampling_distribution_vs_oracle(tiny_f32):
             assert len(counts) > 1 or ref[top] > 0.97
 
 
+def test_sampling_with_unbounded_top_k_vs_oracle(tiny_f32):
+    """G8 corners generate() reaches through infer(top_k=..., top_p=...): top_k = 0 (off), top_k beyond the 128-entry survivor
+    list, top_p = 1.0, a top_p that leaves only min_tokens_to_keep.  The device's processed probability vector equals the
+    oracle's (itself pinned to the HF warpers for these very settings, tests/golden/sampler_kat.npz `*_wide_*`) <= 1e-5 with the
+    same support, every draw lies in that support, and the draw frequencies follow it."""
+    from oracle import gpt as OG
+
+    g, cfg, W, orc, eng = tiny_f32
+    embeds = torch.from_numpy(g["embeds_plain"])
+    P = embeds.shape[0] + 1
+    forced = [11, 4097, 256]
+
+    def replay():
+        eng.prefill(0, embeds, 0)
+        for tok in forced:
+            eng.force_next(0, tok)
+            eng.decode(1, 1, repetition_penalty=10.0)
+
+    replay()
+    logits = torch.from_numpy(eng.read_logits(0))
+    hist = [1] * (P - 1) + [8192] + forced
+    for (T, k, p) in [(0.8, 0, 0.8), (0.9, 500, 0.95), (0.8, 129, 0.6), (1.3, 0, 1.0), (0.8, 0, 0.02), (1.0, 4000, 0.999), (0.8, 9000, 0.9)]:
+        ref = torch.softmax(OG.process_logits(logits, hist, 10.0, T, k if k < 8194 else 0, p, 1), -1).numpy()
+        n_draw = 200 if (T, k, p) == (0.8, 0, 0.8) else 3
+        counts = {}
+        for seed in range(n_draw):
+            replay()
+            eng.decode(1, 1, repetition_penalty=10.0, temperature=T, top_k=k, top_p=p, do_sample=True, seed=500 + seed)
+            tok = int(eng.read(0)[0][len(forced)])
+            counts[tok] = counts.get(tok, 0) + 1
+            assert ref[tok] > 0, (tok, T, k, p)
+        probs = eng.read_probs(0)
+        assert (probs > 0).sum() == (ref > 0).sum(), (T, k, p, (probs > 0).sum(), (ref > 0).sum())
+        assert np.abs(probs - ref).max() <= 1e-5, (T, k, p)
+        if n_draw >= 100:
+            order = np.argsort(-ref)[:3]
+            for t in order:  # three most likely tokens: observed frequency within 4 sigma of p
+                ph, pr = counts.get(int(t), 0) / n_draw, float(ref[t])
+                assert abs(ph - pr) <= 4 * np.sqrt(pr * (1 - pr) / n_draw) + 1e-3, (int(t), ph, pr)
+    # the reference-shaped surface takes the same settings (model_v2.py:724-729)
+    dev = torch.device("cuda:0")
+    eng.store_mel_emb(embeds.unsqueeze(0).to(dev))
+    fk = torch.ones(1, P, dtype=torch.long, device=dev)
+    fk[0, -1] = 8192
+    out = eng.generate(fk, bos_token_id=8192, pad_token_id=8193, eos_token_id=8193, max_length=P + 12, do_sample=True, top_p=0.9, top_k=0,
+                       temperature=0.8, num_beams=1, repetition_penalty=10.0, seed=4)
+    assert out.shape[0] == 1 and P < out.shape[1] <= P + 12
+
+
 def test_typical_sampling_on_device_vs_oracle(tiny_f32):
     """`inference_speech(typical_sampling=True, typical_mass=m)` (model_v2.py:717-722): the TypicalLogitsWarper runs inside the
     sampler kernel between the repetition penalty and the warpers; the processed probability vector matches the oracle
@@ -373,6 +422,57 @@ def test_beam_sample_free_running_and_generate_surface(beam_engines, dev):
                        max_length=P + 20, num_return_sequences=1, do_sample=True, top_p=0.8, top_k=30, temperature=0.8,
                        num_beams=3, repetition_penalty=10.0, length_penalty=0.0, seed=3)
     assert out.shape[0] == 1 and P < out.shape[1] <= P + 20 and int(out[0, P:].max()) < 8194
+
+
+def test_beam_joint_draw_frequencies_match_multinomial_without_replacement(beam_engines):
+    """`_beam_search` draws 2 * num_beams flat indices with `torch.multinomial(probs, 6)` -- WITHOUT replacement
+    (transformers_generation_utils.py:3473-3530).  The device draws them jointly by Gumbel-top-k; here its kept beams are
+    counted over 600 seeds on an 8-token support (top_k 8, top_p 1) and held to the exact law of sequential sampling without
+    replacement (all 8P6 ordered draws enumerated): the 3 kept beams are the 3 best-scoring of the 6 drawn."""
+    import itertools
+
+    from oracle import gpt as OG
+
+    g, engines = beam_engines
+    orc, eng = engines["noeos"]
+    fake, embeds, mask = orc.prepare_gpt_inputs(torch.from_numpy(g["noeos_conds_latent"]), g["noeos_text"])
+    P = len(mask)
+    logits0, _ = orc.prefill(embeds, mask)
+    sc = OG.process_logits(torch.log_softmax(logits0, -1), [1] * (P - 1) + [8192], 10.0, 1.0, 8, 1.0, min_keep=2)
+    toks = torch.nonzero(torch.isfinite(sc)).flatten().tolist()
+    assert len(toks) == 8
+    p = torch.softmax(sc[toks].double(), -1).tolist()
+    score = {t: float(sc[t]) for t in toks}
+    # exact law of the kept set: enumerate the ordered draws of 6 out of 8
+    law = {}
+    for seq in itertools.permutations(range(8), 6):
+        pr, rest = 1.0, 1.0
+        for i in seq:
+            pr *= p[i] / rest
+            rest -= p[i]
+        kept = frozenset(sorted((toks[i] for i in seq), key=lambda t: -score[t])[:3])
+        law[kept] = law.get(kept, 0.0) + pr
+    assert abs(sum(law.values()) - 1.0) < 1e-9
+    N = 600
+    seen = {}
+    for seed in range(N):
+        eng.prefill(0, embeds, 0)
+        eng.beam_begin(3)
+        eng.beam_decode(1, repetition_penalty=10.0, temperature=1.0, top_k=8, top_p=1.0, seed=10_000 + seed)
+        ids, done, s_, bs, lt, src = eng.beam_read(24)
+        kept = frozenset(int(t) for t in lt)
+        assert len(kept) == 3 and kept <= set(toks) and src.tolist() == [0, 0, 0]
+        seen[kept] = seen.get(kept, 0) + 1
+    assert set(seen) <= set(law)
+    # every outcome with a non-negligible probability within 4 sigma; and a chi-square-style total over the common ones
+    chi2, dof = 0.0, 0
+    for kept, pr in law.items():
+        obs = seen.get(kept, 0)
+        assert abs(obs / N - pr) <= 4 * np.sqrt(pr * (1 - pr) / N) + 2e-3, (sorted(kept), obs / N, pr)
+        if pr * N >= 5:
+            chi2 += (obs - pr * N) ** 2 / (pr * N)
+            dof += 1
+    assert dof >= 3 and chi2 <= 2.5 * dof + 10, (chi2, dof)
 
 
 def test_legacy_attention_path(golden, dev, monkeypatch):
