@@ -481,11 +481,16 @@ def main():
             del hp2
             torch.cuda.empty_cache()
         log("extra: decode step per batch size")
-        hpB = make_hotpath(args, dev, "bf16", engine_max, P + 64 + 512, 64, share=hp)
-        hpB.gpt.load_state_dict(Wg)
-        extra["decode_step_by_batch"] = decode_step_by_batch(hpB, P, [b for b in (1, 2, 4, 8, 16) if b <= engine_max])
-        del hpB
-        torch.cuda.empty_cache()
+        # 1..4 sequences: the register GEMVs (what the judged line runs); 5..16: the wide engine (gpt_wide.h), also shown at 4
+        extra["decode_step_by_batch"] = {}
+        for kind, mb_, bs in (("register_gemv", min(4, engine_max), (1, 2, 4)), ("wide_mfma", engine_max, (4, 8, 16))):
+            if kind == "wide_mfma" and engine_max <= 4:
+                continue
+            hpB = make_hotpath(args, dev, "bf16", mb_, P + 64 + 512, 64, share=hp)
+            hpB.gpt.load_state_dict(Wg)
+            extra["decode_step_by_batch"][kind] = decode_step_by_batch(hpB, P, [b for b in bs if b <= mb_])
+            del hpB
+            torch.cuda.empty_cache()
 
     # ---- CPU baseline: the oracle (port of the reference's CPU path) on a bounded sample
     cpu = None

@@ -48,7 +48,10 @@ def traffic(fetch_dir, write_dir, dst, command):
         fi = sum(sum(v["FETCH_SIZE"]) for k, v in fetch.items() if "ixtts" in k)
         wi = sum(sum(v.get("WRITE_SIZE", [])) for k, v in write.items() if "ixtts" in k)
         out["bigvgan_forward"] = {"forwards": n_fwd, "hbm_bytes_per_forward": (2.0 * fi + wi) * 1024.0 / n_fwd,
-                                  "fetch_bytes_per_forward": 2.0 * fi * 1024.0 / n_fwd, "write_bytes_per_forward": wi * 1024.0 / n_fwd}
+                                  "fetch_bytes_per_forward": 2.0 * fi * 1024.0 / n_fwd, "fetch_bytes_per_forward_uncorrected": fi * 1024.0 / n_fwd,
+                                  "write_bytes_per_forward": wi * 1024.0 / n_fwd,
+                                  "caveat": "the x2 FETCH_SIZE correction is calibrated for 16 B/lane streams; the conv x tiles (LDS-DMA, 4 B/lane) and the "
+                                            "Snake passes (4 B/lane) are outside that calibration: the true fetch volume lies between the two figures"}
     json.dump(out, open(dst, "w"), indent=1)
     for k, v in res.items():
         print(f"{v['hbm_bytes_per_launch'] / 1e6:10.3f} MB  x{v['launches']:5d}  {short(k)[:100]}")
@@ -65,11 +68,14 @@ def mfma(d, dst, command):
         m, b = c[k].get("SQ_VALU_MFMA_BUSY_CYCLES", []), c[k].get("SQ_BUSY_CYCLES", [])
         if not m or not b or sum(m) == 0:
             continue
-        res[k] = {"launches": len(m), "SQ_VALU_MFMA_BUSY_CYCLES_sum": sum(m), "SQ_BUSY_CYCLES_sum": sum(b), "mfma_busy_over_sq_busy": sum(m) / max(sum(b), 1.0)}
-    json.dump({"command": command, "note": "quotient of the two counters summed over every dispatch of the kernel in the run (SQ_BUSY_CYCLES is per "
-               "shader engine, SQ_VALU_MFMA_BUSY_CYCLES per SIMD-cycle: compare kernels with each other, not with 1.0)", "kernels": res}, open(dst, "w"), indent=1)
+        q = sum(m) / max(sum(b), 1.0)
+        res[k] = {"launches": len(m), "SQ_VALU_MFMA_BUSY_CYCLES_sum": sum(m), "SQ_BUSY_CYCLES_sum": sum(b), "mfma_busy_over_sq_busy": q,
+                  "mfma_busy_fraction": q / 32.0}
+    json.dump({"command": command, "note": "SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of the 1024 SIMDs, SQ_BUSY_CYCLES the busy cycles of 32 shader-engine "
+               "instances (8 XCDs x 4): mfma_busy_fraction = quotient / 32 = share of SIMD-cycles with the matrix pipe busy.  Calibration: the 128x128 conv "
+               "tile at 105 TFLOP/s = 0.67 of the fp32 MFMA peak reads 0.67.", "kernels": res}, open(dst, "w"), indent=1)
     for k, v in res.items():
-        print(f"{v['mfma_busy_over_sq_busy']:8.3f}  x{v['launches']:5d}  {short(k)[:100]}")
+        print(f"{v['mfma_busy_fraction']:6.3f} busy  x{v['launches']:5d}  {short(k)[:100]}")
 
 
 if __name__ == "__main__":

@@ -34,8 +34,8 @@ constexpr int CG = 8;   // input channels per weight group (one float4 per lane 
 // holding its A operand for the 4 consecutive k-steps of a channel group; a half-wave reads 512 contiguous bytes.
 // They stream from L2 (the XCD-aware tile map keeps one co-slice per XCD) straight into registers, one tap ahead;
 // only the x tile (+dilation halo) lives in LDS.
-template <int MT, int NT, int WM, int WN, int CKG = 4>
-__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
+template <int MT, int NT, int WM, int WN, int CKG = 4, bool RAGGED = true>
+__global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void conv1d_mfma_kernel(ConvParams p) {
   static_assert(CKG == 3 || CKG == 4, "three or four 8-channel groups per chunk");
   constexpr int BM = 32 * MT * WM;
   constexpr int BN = 32 * NT * WN;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           float av = kk == 0 ? a_cur[gg][i].x : kk == 1 ? a_cur[gg][i].y : kk == 2 ? a_cur[gg][i].z : a_cur[gg][i].w;
-          av = live ? av : 0.f;
+          if constexpr (RAGGED) av = live ? av : 0.f;  // (Cin a whole number of chunks: no select + hazard nop between the MFMAs)
 #pragma unroll
           for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[gg & 1][kk][j], acc[i][j], 0, 0, 0);
         }
@@ -228,8 +228,16 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(ConvParams p) {
   }
 }
 
+template <int MT, int NT, int WM, int WN, int CKG = 4, bool RAGGED = true>
+static int launch_cfg_r(const ConvParams& p0, hipStream_t st);
+
 template <int MT, int NT, int WM, int WN, int CKG = 4>
 static int launch_cfg(const ConvParams& p0, hipStream_t st) {
+  return (p0.Cin_pad / CG) % CKG == 0 ? launch_cfg_r<MT, NT, WM, WN, CKG, false>(p0, st) : launch_cfg_r<MT, NT, WM, WN, CKG, true>(p0, st);
+}
+
+template <int MT, int NT, int WM, int WN, int CKG, bool RAGGED>
+static int launch_cfg_r(const ConvParams& p0, hipStream_t st) {
   ConvParams p = p0;
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   p.m_tiles = ceil_div(p.Cout, BM);
@@ -240,7 +248,7 @@ static int launch_cfg(const ConvParams& p0, hipStream_t st) {
   size_t smem = (size_t)(2 * CKG * CG * XWP) * sizeof(float);  // two x-tile buffers
   IX_ARG(smem <= 160 * 1024, "conv: LDS tile %zu B too large", smem);
   IX_ARG(BN + (p.ntap - 1) * adil <= 512, "conv: x tile of %d columns exceeds the staging bound (512)", BN + (p.ntap - 1) * adil);
-  auto kern = conv1d_mfma_kernel<MT, NT, WM, WN, CKG>;
+  auto kern = conv1d_mfma_kernel<MT, NT, WM, WN, CKG, RAGGED>;
   if (smem > 64 * 1024) {
     static bool done = false;
     if (!done) {

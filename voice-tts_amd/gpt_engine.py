@@ -191,8 +191,12 @@ class GptEngine:
                 typical_mass = float(proc.mass)
             else:
                 raise NotImplementedError(f"logits processor {type(proc).__name__} has no device implementation (only typical sampling does)")
-        if inputs.shape[0] != 1 or num_return_sequences != 1:
-            raise NotImplementedError("one sequence per generate() call (autoregressive_batch_size = 1, infer_v2.py:602)")
+        if inputs.shape[0] != 1:
+            raise NotImplementedError("one prompt per generate() call (autoregressive_batch_size = 1, infer_v2.py:602)")
+        nret = int(num_return_sequences)
+        if nret != 1 and (num_beams != 1 or not (1 <= nret <= self.max_batch)):
+            raise NotImplementedError("num_return_sequences > 1 is built for sampling without beams, up to max_batch sequences "
+                                      "(HF expands the prompt and draws independent continuations, generation_utils.py:2128-2135)")
         greedy = (not do_sample) or top_k == 1
         if num_beams != 1 and not (1 <= top_k <= 128):
             raise NotImplementedError("beam-sample keeps at most 128 candidates per beam on the device: 1 <= top_k <= 128 (sampling without beams takes any top_k, 0 = off)")
@@ -221,6 +225,28 @@ class GptEngine:
                 done_steps += n
                 ids, fin = self.beam_read(max_new)[:2]
             out = torch.cat([inputs.reshape(1, -1).to(torch.long).cpu(), torch.from_numpy(ids.astype(np.int64)).reshape(1, -1)], dim=1)
+            return out.to(inputs.device)
+        if nret > 1:
+            # `input_ids.repeat_interleave(num_return_sequences)`: the same prompt in nret slots, each drawing from its own stream
+            # (the slot index is part of the counter-based RNG); rows are right-padded with pad_token_id as HF pads finished rows
+            for b in range(1, nret):
+                self.prefill(b, emb, n_pad)
+            done, fins = 0, [False] * nret
+            rows = [np.zeros(0, np.int32)] * nret
+            while done < max_new and not all(fins):
+                n = min(sync_every, max_new - done)
+                self.decode(nret, n, repetition_penalty=repetition_penalty, temperature=temperature, top_k=top_k, top_p=top_p,
+                            do_sample=not greedy, suppress_stop=suppress_stop, seed=int(unused.get("seed", 0)), typical_mass=typical_mass)
+                done += n
+                for b in range(nret):
+                    rows[b], fins[b] = self.read(b)
+            rows = [r[:max_new] for r in rows]
+            width = max(len(r) for r in rows)
+            pad = int(pad_token_id if pad_token_id is not None else self.cfg["stop_mel_token"])
+            body = np.full((nret, width), pad, np.int64)
+            for b, r in enumerate(rows):
+                body[b, : len(r)] = r
+            out = torch.cat([inputs.reshape(1, -1).to(torch.long).cpu().repeat(nret, 1), torch.from_numpy(body)], dim=1)
             return out.to(inputs.device)
         done = 0
         ids, fin = np.zeros(0, np.int32), False
