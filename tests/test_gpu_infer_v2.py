@@ -272,3 +272,31 @@ def test_model_without_prompt_weights_reports_not_ready():
     assert not m.ready() and "campplus_cn_common.bin" in m.missing_glue
     with pytest.raises(NotImplementedError, match="campplus_cn_common.bin"):
         m.infer(b"RIFF....", "hi", None)
+
+
+def test_http_tts_over_the_real_pipeline(tts_from_dir):
+    """`POST /tts` end to end (server.py:320-440 surface): hex WAV in -> the full pipeline on the GPU -> hex WAV out, through the
+    mirrored FastAPI app around the same `IndexTTS2` the Python-API test uses; emotion label and emotion audio variants."""
+    import io
+
+    from fastapi.testclient import TestClient
+
+    from voice_tts_amd.server import create_app
+
+    m, SM = tts_from_dir
+    spk_hex = SM.synthetic_wav_bytes(1.2, 22050, seed=5).hex()
+    with TestClient(create_app(lambda: m)) as c:
+        assert c.get("/health").json() == {"status": "healthy", "model_loaded": True, "deepspeed_enabled": False}
+        r = c.post("/tts", json={"text": "Hello there.", "spk_audio": spk_hex})
+        assert r.status_code == 200, r.text
+        body = r.json()
+        assert set(body) == {"audio_hex", "audio_length", "inference_time", "rtf", "text"} and body["text"] == "Hello there."
+        with wave.open(io.BytesIO(bytes.fromhex(body["audio_hex"]))) as w:
+            assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 22050)
+            assert w.getnframes() > 0 and abs(w.getnframes() / 22050 - body["audio_length"]) < 1e-6
+        assert body["rtf"] == pytest.approx(body["inference_time"] / body["audio_length"])
+        r = c.post("/tts", json={"text": "Happy.", "spk_audio": spk_hex, "emotion": "高兴", "emo_alpha": 0.6})
+        assert r.status_code == 200, r.text
+        r = c.post("/tts", json={"text": "Emo audio.", "spk_audio": spk_hex, "emo_audio": SM.synthetic_wav_bytes(1.0, 16000, seed=6).hex(), "emo_alpha": 0.5})
+        assert r.status_code == 200, r.text
+        assert c.post("/tts", json={"text": "x", "spk_audio": "zz" * 80}).status_code == 400  # not hex, not a URL
