@@ -211,7 +211,8 @@ class GptEngine:
             n_pad = int((m == 0).sum().item())
             assert n_pad == 0 or bool((m[:n_pad] == 0).all()), "only left padding is produced by prepare_gpt_inputs (model_v2.py:639-642)"
         max_new = (max_length - P) if max_length is not None else (self.max_seq - P - 2)
-        max_new = max(0, min(max_new, self.max_seq - P - 2))
+        # the mel position table bounds what can be embedded (inference_speech's own default cap: max_mel_tokens - 1, model_v2.py:699-703)
+        max_new = max(0, min(max_new, self.max_seq - P - 2, self.cfg["max_mel_tokens"] - 1))
         self.prefill(0, emb, n_pad)
         if num_beams != 1:
             # served default: 3-beam beam-sample (infer_v2.py:598-605,641-658)

@@ -454,7 +454,7 @@ class IndexTTS2:
                 cl = conds_for_segment()
                 fake, embeds, mask = self._prepare_gpt_inputs(cl, tt)
                 n_pad = int((mask == 0).sum().item())
-                max_new = max(0, min(max_mel_tokens, self.gpt.max_seq - fake.shape[1] - 2))
+                max_new = max(0, min(max_mel_tokens, self.gpt.max_seq - fake.shape[1] - 2, self.gpt_cfg["max_mel_tokens"] - 1))
                 todo.append(Segment(0, i, embeds[0], n_pad, max_new, payload=cl))
             pre = [None] * len(segments)
             DecodeScheduler(self.gpt, self.gpt.max_batch, self.stop_mel_token).run(
