@@ -199,8 +199,10 @@ class IndexTTS2:
                     if k in cfg.get("gpt", {}):
                         cond_cfg[k] = {**cond_cfg[k], **{a: b for a, b in cfg["gpt"][k].items() if a in cond_cfg[k]}}
                 # widths the yaml does not spell out are read off the tensors
-                cond_cfg["input_size"] = 2 * gpt_state_dict["conditioning_encoder.embed.out.0.weight"].shape[1] // gpt_state_dict[
-                    "conditioning_encoder.embed.out.0.weight"].shape[0] + 1 if "input_size" not in cfg.get("gpt", {}) else cfg["gpt"]["input_size"]
+                # Conv2dSubsampling2.out is Linear(D * ((idim - 1) // 2), D) (subsampling.py:152-153): only (idim - 1) // 2 enters the
+                # arithmetic; the even idim with that quotient is the feature size of w2v-bert (1024 -> 511)
+                eo = gpt_state_dict["conditioning_encoder.embed.out.0.weight"]
+                cond_cfg["input_size"] = cfg.get("gpt", {}).get("input_size", 2 * (eo.shape[1] // eo.shape[0]) + 2)
                 cond_cfg["perceiver_dim_head"] = gpt_state_dict["perceiver_encoder.layers.0.0.to_q.weight"].shape[0] // cond_cfg["condition_module"]["attention_heads"]
                 cond_cfg["perceiver_depth"] = len({k.split(".")[2] for k in gpt_state_dict if k.startswith("perceiver_encoder.layers.")})
                 cond_cfg["cnn_kernel"] = gpt_state_dict["conditioning_encoder.encoders.0.conv_module.depthwise_conv.weight"].shape[-1]
