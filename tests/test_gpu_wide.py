@@ -59,6 +59,14 @@ def test_wide_tokens_and_logits_do_not_depend_on_company(dev):
     eng.decode(8, n, repetition_penalty=10.0, suppress_stop=True)
     for b in range(8):
         assert eng.read(b)[0][:n].tolist() == alone[7 - b][1]
+    # all 16 columns of the MFMA in use (the largest engine): each prompt twice, every copy as alone on the 8-slot engine
+    big = GptEngine(cfg, dtype="bf16", max_seq=160, max_batch=16, device=dev).load_state_dict(W)
+    for b in range(16):
+        big.prefill(b, *P[b % 8])
+    big.decode(16, n, repetition_penalty=10.0, suppress_stop=True)
+    for b in range(16):
+        assert big.read(b)[0][:n].tolist() == alone[b % 8][1], b
+        assert np.array_equal(big.read_logits(b), alone[b % 8][2]), b
 
 
 def test_wide_agrees_with_the_register_gemvs_and_the_bf16_rounded_oracle(dev):
