@@ -71,8 +71,11 @@ def parse(argv=None):
     ap.add_argument("--concurrency", type=int, default=1, help="requests in flight per GPU: their segments share the decode slots through the "
                     "continuous-batching scheduler (row N3); 1 = BASELINE configs[1], the judged line")
     ap.add_argument("--no-cond", action="store_true", help="leave the conditioning encoders out of the timed region (feed a synthetic conds_latent)")
-    ap.add_argument("--decode", default="greedy", choices=["greedy", "beam"], help="greedy: BASELINE configs[1] (the judged line); beam: the served "
-                    "default of configs[2] -- 3-beam beam-sample, top_k 30, top_p 0.8, temperature 0.8 -- one segment at a time")
+    ap.add_argument("--decode", default="greedy", choices=["greedy", "beam", "sample"], help="greedy: BASELINE configs[1] (the judged line); beam: the "
+                    "served default -- 3-beam beam-sample, top_k 30, top_p 0.8, temperature 0.8 -- one segment at a time; sample: BASELINE configs[2] -- "
+                    "top-p sampling without beams (top_p 0.8, top_k 30, temperature 0.8), both segments together")
+    ap.add_argument("--emo-alpha", type=float, default=None, help="BASELINE configs[2]: a separate emotion prompt (5 s, 249 w2v-bert frames) merged with this "
+                    "alpha (0.7) in the conditioning encoders (merge_emovec, model_v2.py:742-747)")
     ap.add_argument("--bigvgan-only", action="store_true", help="BASELINE configs[4]: 1000-frame random mel -> waveform microbench (20 warm-up + 100 timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -165,12 +168,13 @@ class Workload:
         g, dev = self.g, self.dev
         return dict(spk_cond_emb=torch.randn(1, 249, 1024, generator=g).to(dev), prompt_condition=torch.randn(1, self.Tref, 512, generator=g).to(dev),
                     ref_mel=(torch.randn(1, 80, self.Tref, generator=g) * 2 - 4).clamp(-11.5, 2).to(dev), style=torch.randn(1, 192, generator=g).to(dev),
-                    conds=(torch.randn(34, self.D, generator=g) * 0.5).to(dev))
+                    emo_cond_emb=torch.randn(1, 249, 1024, generator=g).to(dev), conds=(torch.randn(34, self.D, generator=g) * 0.5).to(dev))
 
     def conds(self, pr):
         if not self.use_cond:
             return pr["conds"]
-        cl = self.hp.conds_from_prompt(pr["spk_cond_emb"])  # merge_emovec + get_conditioning (infer_v2.py:629-635), once per request
+        ea = self.args.emo_alpha
+        cl = self.hp.conds_from_prompt(pr["spk_cond_emb"], pr["emo_cond_emb"] if ea is not None else None, ea if ea is not None else 1.0)  # merge_emovec + get_conditioning (infer_v2.py:629-635), once per request
         # synthetic encoder weights give arbitrary latent statistics; keep the GPT prefix at the scale it is built for
         return cl * (0.5 / cl.std().clamp_min(1e-6))
 
@@ -224,7 +228,8 @@ def run_request(wl, hp, pr, texts, n_codes, mode, R=1, acc=None):
             hp.gpt.beam_decode(n_codes, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=True, seed=7)
             many.append(hp.gpt.beam_read(n_codes)[0][:n_codes])
     elif len(prompts) <= hp.gpt.max_batch:
-        many = hp.generate(prompts, n_codes, repetition_penalty=10.0, fixed_length=True)
+        samp = dict(do_sample=True, temperature=0.8, top_k=30, top_p=0.8, seed=7) if mode == "sample" else {}
+        many = hp.generate(prompts, n_codes, repetition_penalty=10.0, fixed_length=True, **samp)
     else:
         many = hp.generate_many([(e, p, n_codes) for (e, p) in prompts], fixed_length=True, repetition_penalty=10.0)
     t1 = tick()
@@ -454,7 +459,7 @@ def main():
 
     # ---- extra figures of the default line (driver-visible): config 5, the served 3-beam default, fp32 parity mode, step per B
     extra = None
-    default_line = world == 1 and not mixed and R == 1 and args.decode == "greedy" and args.dtype == "bf16" and not args.no_extra
+    default_line = world == 1 and not mixed and R == 1 and args.decode == "greedy" and args.dtype == "bf16" and not args.no_extra and args.emo_alpha is None
     if rank == 0 and default_line:
         extra = {}
         log("extra: BigVGAN config-5 microbench")
@@ -576,7 +581,9 @@ def main():
             workload = ((f"1 /tts request per GPU: " if R == 1 else f"{R} concurrent /tts requests per GPU (segments share the decode slots, continuous batching B<={max_batch}), each ")
                         + f"{n_seg}x{n_tok}-token zh text segments (200-char utterance), "
                         + ("conditioning encoders on 249 prompt frames (conformer + perceiver, PyTorch-ROCm glue, fp32), " if use_cond else "")
+                        + (f"emotion prompt merged at alpha {args.emo_alpha}, " if args.emo_alpha is not None else "")
                         + (f"greedy fixed-length decode {n_codes} codes/segment batched B={min(n_seg, max_batch)}, " if args.decode == "greedy" else
+                           f"top-p sampling (top_p 0.8, top_k 30, T 0.8, theta 10) fixed-length decode {n_codes} codes/segment batched B={min(n_seg, max_batch)}, " if args.decode == "sample" else
                            f"3-beam beam-sample (top_k 30, top_p 0.8, T 0.8, theta 10) fixed-length decode {n_codes} codes/segment, segments in turn, ")
                         + "latent GPT forward, "
                         + ("s2mel (length regulator + 25-step CFM/DiT, PyTorch-ROCm glue, fp32, 430-frame prompt), " if use_s2mel else "s2mel skipped (synthetic mel), ")

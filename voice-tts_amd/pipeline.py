@@ -101,8 +101,9 @@ class HotPath:
         return torch.cat((conds_latent.to(self.device, torch.float32), temb), 0)
 
     # ------------------------------------------------------------------ G1-G8
-    def generate(self, prompts, max_new, repetition_penalty=10.0, fixed_length=False, sync_every=64):
-        """Greedy decode of up to `max_batch` independent sequences together.
+    def generate(self, prompts, max_new, repetition_penalty=10.0, fixed_length=False, sync_every=64, **sampler):
+        """Decode up to `max_batch` independent sequences together: greedy by default, multinomial sampling with
+        `do_sample=True, temperature=, top_k=, top_p=, seed=` (each slot draws from its own counter-based stream).
 
         prompts: list of (embeds [P-1,D], n_left_pad).  Returns a list of int32 id arrays,
         trimmed at the first stop token (inclusive), as `generate()` would return them.
@@ -115,7 +116,7 @@ class HotPath:
         out = [None] * B
         while done < max_new:
             n = min(sync_every, max_new - done)
-            self.gpt.decode(B, n, repetition_penalty=repetition_penalty, suppress_stop=fixed_length)
+            self.gpt.decode(B, n, repetition_penalty=repetition_penalty, suppress_stop=fixed_length, **sampler)
             done += n
             fins = []
             for b in range(B):
