@@ -300,3 +300,46 @@ def test_http_tts_over_the_real_pipeline(tts_from_dir):
         r = c.post("/tts", json={"text": "Emo audio.", "spk_audio": spk_hex, "emo_audio": SM.synthetic_wav_bytes(1.0, 16000, seed=6).hex(), "emo_alpha": 0.5})
         assert r.status_code == 200, r.text
         assert c.post("/tts", json={"text": "x", "spk_audio": "zz" * 80}).status_code == 400  # not hex, not a URL
+
+
+def test_infer_many_shares_the_decode_slots(tts_from_dir):
+    """`IndexTTS2.infer_many` (row N3 at the API level): three requests with different prompts, texts and emotion settings through ONE
+    scheduler run.  With `top_k=1` the decode is deterministic: every request's audio has the length its own `infer(...,
+    num_beams=1, top_k=1)` produces (same codes: a sequence's tokens do not depend on the company it decodes in), int16 mono."""
+    m, SM = tts_from_dir
+    wav_a, wav_b = SM.synthetic_wav_bytes(1.5, 24000), SM.synthetic_wav_bytes(1.0, 16000, seed=1)
+    reqs = [dict(spk_audio_prompt=wav_a, text="Hello world, this is a test. 你好世界！"),
+            dict(spk_audio_prompt=wav_b, text="Short."),
+            dict(spk_audio_prompt=wav_a, text="Vector.", emo_vector=[0.3, 0, 0, 0, 0, 0, 0.2, 0.1])]
+    outs = m.infer_many(reqs, decode_slots=4, top_k=1, max_mel_tokens=20)
+    assert len(outs) == 3 and m.last_timing["audio_length"] > 0
+    for rq, (sr, pcm) in zip(reqs, outs):
+        assert sr == 22050 and pcm.dtype == np.int16 and pcm.ndim == 2 and pcm.shape[1] == 1
+        kw = {k: rq[k] for k in ("emo_vector",) if k in rq}
+        ref_sr, ref = m.infer(rq["spk_audio_prompt"], rq["text"], None, num_beams=1, top_k=1, max_mel_tokens=20, **kw)
+        assert ref.shape == pcm.shape, (rq["text"], ref.shape, pcm.shape)
+    assert m.infer_many([dict(spk_audio_prompt=wav_a, text="")])[0] is None
+
+
+def test_http_batched_mode_over_the_real_pipeline(tts_from_dir, monkeypatch):
+    """IXTTS_BATCH_SLOTS: three concurrent POST /tts served by one `infer_many` batch on the GPU."""
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+
+    from fastapi.testclient import TestClient
+
+    from voice_tts_amd.server import create_app
+
+    m, SM = tts_from_dir
+    monkeypatch.setenv("IXTTS_BATCH_SLOTS", "4")
+    monkeypatch.setenv("IXTTS_BATCH_WINDOW_MS", "300")
+    spk_hex = SM.synthetic_wav_bytes(1.2, 22050, seed=5).hex()
+    app = create_app(lambda: m)
+    with TestClient(app) as c:
+        with ThreadPoolExecutor(3) as ex:
+            rs = list(ex.map(lambda t: c.post("/tts", json={"text": t, "spk_audio": spk_hex}), ["One.", "Two two.", "Three three three."]))
+        assert [r.status_code for r in rs] == [200, 200, 200], [r.text[:200] for r in rs]
+        assert max(app.state.tts["batcher"].batches) >= 2
+        for r in rs:
+            with wave.open(io.BytesIO(bytes.fromhex(r.json()["audio_hex"]))) as w:
+                assert w.getframerate() == 22050 and w.getnframes() > 0

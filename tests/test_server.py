@@ -128,3 +128,38 @@ def test_emotion_vocabulary_equals_the_reference_for_every_label():
         assert EM.create_emotion_vector(c["label"], c["alpha"]) == c["vector"], c
     for c in g["dict_cases"]:
         assert EM.create_emotion_vector(c["input"]) == c["vector"], c
+
+
+def test_opt_in_request_batching_replaces_the_lock(monkeypatch):
+    """IXTTS_BATCH_SLOTS=N (SURVEY 8(f) N3 at the server): concurrent /tts requests are served through `model.infer_many` in
+    batches instead of one at a time behind the lock; same response model, a failing batch answers 500."""
+    import threading
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+
+    class BatchStub(StubTTS):
+        def __init__(self):
+            super().__init__()
+            self.batches, self.gate = [], threading.Event()
+
+        def infer_many(self, requests, decode_slots=8, **kw):
+            self.batches.append([r["text"] for r in requests])
+            if any(r["text"] == "boom" for r in requests):
+                raise RuntimeError("kernel exploded")
+            time.sleep(0.05)
+            return [(22050, (np.arange(2205 * (1 + i)) % 100).astype(np.int16).reshape(-1, 1)) for i, _ in enumerate(requests)]
+
+    monkeypatch.setenv("IXTTS_BATCH_SLOTS", "4")
+    monkeypatch.setenv("IXTTS_BATCH_WINDOW_MS", "150")
+    stub = BatchStub()
+    with TestClient(create_app(lambda: stub)) as c:
+        with ThreadPoolExecutor(3) as ex:
+            rs = list(ex.map(lambda t: c.post("/tts", json={"text": t, "spk_audio": HEX, "emotion": "sad"}), ["a", "b", "c"]))
+        assert [r.status_code for r in rs] == [200, 200, 200]
+        assert sorted(sum(stub.batches, [])) == ["a", "b", "c"] and max(len(b) for b in stub.batches) >= 2 and not stub.calls  # infer() never ran
+        for r in rs:
+            body = r.json()
+            with wave.open(io.BytesIO(bytes.fromhex(body["audio_hex"]))) as w:
+                assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 22050)
+                assert abs(w.getnframes() / 22050 - body["audio_length"]) < 1e-9
+        assert c.post("/tts", json={"text": "boom", "spk_audio": HEX}).status_code == 500

@@ -182,6 +182,9 @@ class IndexTTS2:
         self.bigvgan = BigVGAN(bcfg, use_cuda_kernel=True, max_frames=max_frames, device=self.device)
         self.gpt.load_state_dict(gpt_state_dict)
         self.bigvgan.load_state_dict(bigvgan_state_dict)
+        self._gpt_tensors = {k: v for k, v in gpt_state_dict.items() if k.startswith(("gpt.h.", "gpt.ln_f.", "final_norm.", "mel_head.", "mel_embedding.",
+                                                                                       "mel_pos_embedding."))}  # for infer_many's engine
+        self._many = None
         D = gcfg["model_dim"]
         self.text_embedding = gpt_state_dict["text_embedding.weight"].to(self.device, torch.float32)
         self.text_pos_embedding = gpt_state_dict["text_pos_embedding.emb.weight"].to(self.device, torch.float32)
@@ -363,6 +366,123 @@ class IndexTTS2:
             return list(gen)[0]
         except IndexError:
             return None
+
+    # ------------------------------------------------------------------ row N3 at the API level: requests decoded together
+    def _many_engine(self, slots):
+        """A second decode engine whose slots are shared by the segments of several requests (wide MFMA GEMVs above 4 slots,
+        bf16 only; an fp32 model keeps 4)."""
+        from . import _lib
+
+        slots = max(1, min(int(slots), _lib.max_batch() if self.use_fp16 else 4))
+        if self._many is None or self._many.max_batch != slots:
+            self._many = GptEngine(self.gpt_cfg, dtype="bf16" if self.use_fp16 else "f32", max_seq=self.gpt.max_seq, max_batch=slots, device=self.device)
+            self._many.load_state_dict(self._gpt_tensors)
+        return self._many
+
+    @torch.no_grad()
+    def infer_many(self, requests, interval_silence=200, max_text_tokens_per_segment=120, decode_slots=8, **generation_kwargs):
+        """Several `/tts` requests served TOGETHER (the worker's global lock, server.py:25,384, replaced by the
+        decode scheduler): every request's segments share the decode slots -- the weights are read once per step for all of them
+        -- and the post-decode stages run per segment as in `infer`.  Each request is a dict with `spk_audio_prompt`, `text` and
+        optionally `emo_audio_prompt`, `emo_alpha`, `emo_vector`, `use_random`.  Decoding is sampling WITHOUT beams (the beams of
+        one request would take the slots the others use; `num_beams` is ignored), deterministic argmax when `top_k == 1`; the
+        other generation kwargs and defaults are `infer`'s.  Returns one `(22050, int16 [N, 1])` (or None: empty text) per request."""
+        from .scheduler import DecodeScheduler, Segment
+
+        generation_kwargs.pop("do_sample", True)
+        top_p = generation_kwargs.pop("top_p", 0.8)
+        top_k = generation_kwargs.pop("top_k", 30)
+        temperature = generation_kwargs.pop("temperature", 0.8)
+        generation_kwargs.pop("num_beams", None)
+        generation_kwargs.pop("length_penalty", None)
+        repetition_penalty = generation_kwargs.pop("repetition_penalty", 10.0)
+        max_mel_tokens = generation_kwargs.pop("max_mel_tokens", 1500)
+        speaker_fn = self._stage("speaker", self.prompt.speaker if self.prompt else None)
+        emotion_fn = self._stage("emotion", self.prompt.emotion if self.prompt else None)
+        eng = self._many_engine(decode_slots)
+        start = time.perf_counter()
+        plans, todo = [], []
+        for ri, rq in enumerate(requests):
+            spk_prompt, emo_prompt = rq["spk_audio_prompt"], rq.get("emo_audio_prompt")
+            emo_alpha, emo_vector = rq.get("emo_alpha", 1.0), rq.get("emo_vector")
+            if emo_vector is not None:  # infer_v2.py:476-505
+                emo_prompt = None
+                scale = max(0.0, min(1.0, emo_alpha))
+                if scale != 1.0:
+                    emo_vector = [int(x * scale * 10000) / 10000 for x in emo_vector]
+            if emo_prompt is None:
+                emo_prompt, emo_alpha = spk_prompt, 1.0
+            if self.cache_spk is None or not _same_prompt(self.cache_spk_audio_prompt, spk_prompt):
+                self.cache_spk, self.cache_spk_audio_prompt = speaker_fn(spk_prompt), spk_prompt
+            spk = self.cache_spk
+            if self.cache_emo_cond is None or not _same_prompt(self.cache_emo_audio_prompt, emo_prompt):
+                self.cache_emo_cond, self.cache_emo_audio_prompt = emotion_fn(emo_prompt), emo_prompt
+            emo_cond = self.cache_emo_cond
+            if self.cond is not None:
+                sc, ec = spk["spk_cond_emb"].to(self.device, torch.float32), emo_cond.to(self.device, torch.float32)
+                ls, le = torch.tensor([sc.shape[-1]], device=self.device), torch.tensor([ec.shape[-1]], device=self.device)
+                emovec = self.cond.merge_emovec(sc, ec, ls, le, alpha=emo_alpha)
+                cond32 = self.cond.get_conditioning(sc.transpose(1, 2), ls)[0]
+            else:
+                emovec = self._stage("merge_emovec", None)(spk["spk_cond_emb"], emo_cond, emo_alpha)
+                cond32 = self._stage("get_conditioning", None)(spk["spk_cond_emb"])
+            if emo_vector is not None:
+                mix = self._stage("emo_vector_mix", (lambda v, st, r: self._builtin_emo_mix(v, st, r)) if self.emo_matrix is not None else None)
+                emovec_mat, weight_sum = mix(emo_vector, spk["style"], rq.get("use_random", False))
+                emovec = emovec_mat + (1 - weight_sum) * emovec
+            cl = torch.cat((cond32 + emovec.reshape(1, -1), self.speed_emb[1:2], self.speed_emb[0:1]), 0)
+            if self.tokenizer is not None:
+                toks = self.tokenizer.tokenize(rq["text"])
+                segments = [self.tokenizer.convert_tokens_to_ids(sent) for sent in self.tokenizer.split_segments(toks, max_text_tokens_per_segment)]
+            else:
+                segments = self._stage("tokenize", None)(rq["text"], max_text_tokens_per_segment, 0)
+            plans.append(dict(spk=spk, cl=cl, segments=segments, codes=[None] * len(segments)))
+            for si, ids in enumerate(segments):
+                tt = torch.as_tensor(ids, dtype=torch.int32, device=self.device).reshape(-1)
+                fake, embeds, mask = self._prepare_gpt_inputs(cl, tt)
+                n_pad = int((mask == 0).sum().item())
+                max_new = max(0, min(max_mel_tokens, eng.max_seq - fake.shape[1] - 2, self.gpt_cfg["max_mel_tokens"] - 1))
+                todo.append(Segment(ri, si, embeds[0], n_pad, max_new))
+        greedy = top_k == 1
+        if todo:
+            DecodeScheduler(eng, eng.max_batch, self.stop_mel_token).run(
+                todo, lambda seg, ids: plans[seg.request]["codes"].__setitem__(seg.index, ids), repetition_penalty=repetition_penalty,
+                temperature=temperature, top_k=top_k, top_p=top_p, do_sample=not greedy, seed=int(generation_kwargs.get("seed", 0)))
+        torch.cuda.synchronize(self.device)
+        t_decode = time.perf_counter() - start
+        out = []
+        for plan in plans:
+            wavs = []
+            for ids, seg in zip(plan["codes"], plan["segments"]):
+                row = torch.from_numpy(np.asarray(ids).astype(np.int64)).to(self.device)
+                stops = (row == self.stop_mel_token).nonzero(as_tuple=False)
+                n = int(stops[0]) if stops.numel() else row.numel()
+                if n == 0:
+                    continue
+                codes = row[:n].reshape(1, -1)
+                tt = torch.as_tensor(seg, dtype=torch.int32, device=self.device).reshape(-1)
+                t = torch.cat((tt.new_tensor([self.gpt_cfg["start_text_token"]]), tt, tt.new_tensor([self.gpt_cfg["stop_text_token"]]))).long()
+                prefix = torch.cat((plan["cl"], self.text_embedding[t] + self.text_pos_embedding[: t.numel()]), 0)
+                latent = self.gpt.latent(prefix, codes[0]).unsqueeze(0)
+                lens = torch.tensor([n], dtype=torch.long, device=self.device)
+                spk = plan["spk"]
+                if self.s2mel is not None:
+                    mel = self.s2mel(latent, codes, lens, spk["prompt_condition"], spk["ref_mel"], spk["style"], n_timesteps=25, inference_cfg_rate=0.7)
+                else:
+                    mel = self._stage("s2mel", None)(latent, codes, lens, spk)
+                wav = torch.clamp(32767 * self.bigvgan(mel.float()).squeeze().unsqueeze(0), -32767.0, 32767.0)
+                wavs.append(wav.cpu())
+            if not wavs:
+                out.append(None)
+                continue
+            wav = torch.cat(self.insert_interval_silence(wavs, sampling_rate=22050, interval_silence=interval_silence), dim=1)
+            out.append((22050, wav.type(torch.int16).numpy().T))
+        total = time.perf_counter() - start
+        audio = sum(o[1].shape[0] for o in out if o is not None) / 22050.0
+        logger.info(f"infer_many: {len(requests)} requests, {len(todo)} segments, decode {t_decode:.2f} s, total {total:.2f} s, "
+                    f"audio {audio:.2f} s, RTF {total / max(audio, 1e-9):.4f}")
+        self.last_timing = dict(gpt_gen_time=t_decode, total=total, audio_length=audio)
+        return out
 
     def infer_generator(self, spk_audio_prompt, text, output_path, emo_audio_prompt=None, emo_alpha=1.0, emo_vector=None,
                         use_emo_text=False, emo_text=None, use_random=False, interval_silence=200, verbose=False,

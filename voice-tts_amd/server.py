@@ -119,8 +119,51 @@ def default_model_factory():
     return IndexTTS2(cfg_path="models/IndexTTS/config.yaml", model_dir="models/IndexTTS", use_fp16=True, use_cuda_kernel=True, use_deepspeed=False)
 
 
+class RequestBatcher:
+    """Opt-in replacement of the per-worker inference lock (server.py:25,384) by the decode scheduler: handlers
+    queue their request; one thread takes what has arrived within `window_s` (at most `slots` requests) and serves the batch
+    through `model.infer_many` -- every request's segments share the decode slots.  Decoding in this mode is sampling without
+    beams (see `IndexTTS2.infer_many`), which is why it is not the default."""
+
+    def __init__(self, model, slots, window_s=0.02):
+        import queue
+        from concurrent.futures import Future
+
+        self.model, self.slots, self.window_s, self._Future = model, int(slots), float(window_s), Future
+        self.q = queue.Queue()
+        self.batches = []  # sizes of the batches served (observability / tests)
+        self._t = threading.Thread(target=self._loop, name="ixtts-batcher", daemon=True)
+        self._t.start()
+
+    def submit(self, request):
+        fut = self._Future()
+        self.q.put((request, fut))
+        return fut
+
+    def _loop(self):
+        import queue
+
+        while True:
+            batch = [self.q.get()]
+            deadline = time.time() + self.window_s
+            while len(batch) < self.slots:
+                try:
+                    batch.append(self.q.get(timeout=max(0.0, deadline - time.time())))
+                except queue.Empty:
+                    break
+            self.batches.append(len(batch))
+            try:
+                results = self.model.infer_many([r for r, _ in batch], decode_slots=self.slots)
+                for (_, fut), res in zip(batch, results):
+                    fut.set_result(res)
+            except Exception as e:  # one failure fails the batch it was in, as the lock-step path fails its request
+                for _, fut in batch:
+                    if not fut.done():
+                        fut.set_exception(e)
+
+
 def create_app(model_factory=default_model_factory):
-    state = {"model": None}
+    state = {"model": None, "batcher": None}
     inference_lock = threading.Lock()
 
     @asynccontextmanager
@@ -131,6 +174,10 @@ def create_app(model_factory=default_model_factory):
         try:
             state["model"] = model_factory()
             logger.info(f"Model loaded successfully on GPU: {visible}")
+            slots = int(os.environ.get("IXTTS_BATCH_SLOTS", "0") or 0)
+            if slots > 0 and hasattr(state["model"], "infer_many"):
+                state["batcher"] = RequestBatcher(state["model"], slots, float(os.environ.get("IXTTS_BATCH_WINDOW_MS", "20")) / 1e3)
+                logger.info(f"Request batching on: up to {slots} decode slots per step (IXTTS_BATCH_SLOTS)")
         except Exception as e:
             logger.error(f"Failed to load model: {e}")
             raise
@@ -193,9 +240,28 @@ def create_app(model_factory=default_model_factory):
                     emo_vector = create_emotion_vector(request.emotion, request.emo_alpha)
                 else:
                     emo_vector = create_emotion_vector(request.emotion)
+            start = time.time()
+            if state["batcher"] is not None:  # opt-in: queued requests decode together (IXTTS_BATCH_SLOTS)
+                import io
+
+                res = state["batcher"].submit(dict(spk_audio_prompt=spk_audio_data, text=request.text, emo_audio_prompt=emo_audio_data if emo_audio_data else None,
+                                                   emo_alpha=request.emo_alpha if emo_audio_data else 1.0, emo_vector=emo_vector)).result()
+                if res is None:
+                    raise RuntimeError("the text produced no speech segment")
+                sr, pcm = res
+                buf = io.BytesIO()
+                with wave.open(buf, "wb") as w:
+                    w.setnchannels(pcm.shape[1])
+                    w.setsampwidth(2)
+                    w.setframerate(sr)
+                    w.writeframes(pcm.astype("<i2").tobytes())
+                inference_time = time.time() - start
+                audio_length = pcm.shape[0] / float(sr)
+                rtf = inference_time / audio_length if audio_length > 0 else 0.0
+                logger.info(f"TTS completed (batched): audio_length={audio_length:.2f}s, inference_time={inference_time:.2f}s, rtf={rtf:.4f}")
+                return TTSResponse(audio_hex=buf.getvalue().hex(), audio_length=audio_length, inference_time=inference_time, rtf=rtf, text=request.text)
             with tempfile.NamedTemporaryFile(suffix=".wav", delete=False) as tmp:
                 output_path = tmp.name
-            start = time.time()
             with inference_lock:  # one inference at a time per worker (server.py:25,384)
                 result_path = model.infer(spk_audio_prompt=spk_audio_data, text=request.text, output_path=output_path,
                                           emo_audio_prompt=emo_audio_data if emo_audio_data else None,
