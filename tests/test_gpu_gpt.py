@@ -430,6 +430,42 @@ def test_beam_sample_free_running_and_generate_surface(beam_engines, dev):
     assert out.shape[0] == 1 and P < out.shape[1] <= P + 20 and int(out[0, P:].max()) < 8194
 
 
+def test_beam_kv_reorder_moves_only_unshared_rows_same_result(beam_engines, dev, monkeypatch):
+    """`_reorder_cache` (model_v2.py:199-212) index_selects every K/V row; the device moves only the rows two slots do not
+    already share (gpt_beam.hip: beam_reorder_kv_kernel).  Same free-running 3-beam decode on an engine that moves every row
+    (IXTTS_BEAM_REORDER=full): tokens, source beams and beam scores must agree bit for bit, step by step."""
+    import voice_tts_amd.weights as WR
+    from voice_tts_amd.gpt_engine import GptEngine
+
+    g, engines = beam_engines
+    orc, eng = engines["noeos"]
+    fake, embeds, mask = orc.prepare_gpt_inputs(torch.from_numpy(g["noeos_conds_latent"]), g["noeos_text"])
+    cfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2)
+    W = WR.make_gpt_weights(cfg, seed=int(g["seed"]), head_scale=50.0)
+    W["mel_head.bias"] = W["mel_head.bias"].clone()
+    W["mel_head.bias"][8193] += float(g["noeos_stop_bias"])
+    monkeypatch.setenv("IXTTS_BEAM_REORDER", "full")
+    full = GptEngine(cfg, dtype="f32", max_seq=128, max_batch=3, device=dev).load_state_dict(W)
+    monkeypatch.delenv("IXTTS_BEAM_REORDER")
+    n_src_patterns = set()
+    for seed in (1, 2, 3):
+        for e in (eng, full):
+            e.prefill(0, embeds, 0)
+            e.beam_begin(3)
+        for step in range(40):
+            outs = []
+            for e in (eng, full):
+                # (temperature 3: flat enough that the beams keep swapping ancestors)
+                e.beam_decode(1, repetition_penalty=10.0, temperature=3.0, top_k=30, top_p=0.95, suppress_stop=True, seed=seed)
+                outs.append(e.beam_read(64))
+            (ids_a, done_a, sc_a, bs_a, lt_a, src_a), (ids_b, done_b, sc_b, bs_b, lt_b, src_b) = outs
+            assert lt_a.tolist() == lt_b.tolist() and src_a.tolist() == src_b.tolist(), (seed, step)
+            assert np.array_equal(bs_a, bs_b), (seed, step, bs_a, bs_b)
+            n_src_patterns.add(tuple(src_a.tolist()))
+        assert ids_a.tolist() == ids_b.tolist()
+    assert len(n_src_patterns) >= 4, n_src_patterns  # identity, collapses onto one beam, swaps
+
+
 def test_beam_joint_draw_frequencies_match_multinomial_without_replacement(beam_engines):
     """`_beam_search` draws 2 * num_beams flat indices with `torch.multinomial(probs, 6)` -- WITHOUT replacement
     (transformers_generation_utils.py:3473-3530).  The device draws them jointly by Gumbel-top-k; here its kept beams are

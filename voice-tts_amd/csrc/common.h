@@ -1,5 +1,6 @@
 // common.h -- shared host/device helpers for libixtts_hip.so (gfx950 only).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
@@ -74,6 +75,36 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
+}
+// the same on DPP (lanes without a source keep their own value): the maximum lands in lane 63, then goes to every lane
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_take_or_self(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  float s = fmaxf(v, dpp_take_or_self<0x111, 0xf, 0xf>(v));  // row_shr:1
+  s = fmaxf(s, dpp_take_or_self<0x112, 0xf, 0xf>(v));        // row_shr:2
+  s = fmaxf(s, dpp_take_or_self<0x113, 0xf, 0xf>(v));        // row_shr:3
+  s = fmaxf(s, dpp_take_or_self<0x114, 0xf, 0xe>(s));        // row_shr:4
+  s = fmaxf(s, dpp_take_or_self<0x118, 0xf, 0xc>(s));        // row_shr:8
+  s = fmaxf(s, dpp_take_or_self<0x142, 0xa, 0xf>(s));        // row_bcast:15
+  s = fmaxf(s, dpp_take_or_self<0x143, 0xc, 0xf>(s));        // row_bcast:31
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 63));
+}
+// inclusive prefix sums over the wave's lanes (the scan wave_sum63 is built on), unsigned
+__device__ __forceinline__ unsigned int wave_scan_u32(unsigned int v) {
+  auto take = [](unsigned int x, auto ctrl, auto rm, auto bm) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, decltype(ctrl)::value, decltype(rm)::value, decltype(bm)::value, true);
+  };
+  using std::integral_constant;
+  unsigned int s = v + take(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});
+  s += take(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});
+  s += take(v, integral_constant<int, 0x113>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});
+  s += take(s, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xe>{});
+  s += take(s, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xc>{});
+  s += take(s, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, integral_constant<int, 0xf>{});
+  s += take(s, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}, integral_constant<int, 0xf>{});
+  return s;
 }
 
 }  // namespace ixtts

@@ -452,6 +452,7 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   ok &= hipMalloc(&h->beam_cand_v, (size_t)MAXB * SAMP_MAXK * 4) == hipSuccess;
   ok &= hipMalloc(&h->beam_cand_i, (size_t)MAXB * SAMP_MAXK * 4) == hipSuccess;
   ok &= hipMalloc(&h->beam_cand_n, (size_t)MAXB * 4) == hipSuccess;
+  ok &= hipMalloc(&h->beam_lcp, (size_t)(MAXB * MAXB + MAXB) * 4) == hipSuccess;
   ok &= hipMalloc(&h->probs, (size_t)S * V * 4) == hipSuccess;
   h->scratch_floats = (size_t)FF * D;
   ok &= hipMalloc(&h->scratch, h->scratch_floats * 4) == hipSuccess;
@@ -468,6 +469,7 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   if (const char* e = getenv("IXTTS_ATTN")) h->attn_split = strcmp(e, "legacy") != 0;
   h->wide = c->max_batch > MAXB_REG;
   if (const char* e = getenv("IXTTS_WIDE")) h->wide = h->wide || (strcmp(e, "1") == 0 && c->weight_dtype == IXTTS_DTYPE_BF16);  // A/B: small batches on the MFMA GEMVs
+  if (const char* e = getenv("IXTTS_BEAM_REORDER")) h->beam_every_row = strcmp(e, "full") == 0;
   if (h->wide) h->attn_split = false;  // one workgroup per (head, slot): see forward_layers_wide
   memset(h->host_prompt_len, 0, sizeof(h->host_prompt_len));
   memset(h->host_gen_est, 0, sizeof(h->host_gen_est));
@@ -770,6 +772,7 @@ extern "C" int ixtts_gpt_beam_begin(ixtts_gpt* h, int num_beams, void* stream) {
   IX_HIP(hipMemsetAsync(h->n_hyp, 0, 4, st));
   IX_HIP(hipMemsetAsync(h->beam_done, 0, 4, st));
   IX_HIP(hipMemsetAsync(h->beam_forced_flag, 0, 4, st));
+  IX_HIP(hipMemsetAsync(h->beam_lcp, 0, (size_t)(MAXB * MAXB + MAXB) * 4, st));  // no generated rows yet
   IX_HIP(hipStreamSynchronize(st));  // bs / worst are stack variables
   h->num_beams = num_beams;
   return IXTTS_OK;
@@ -1022,7 +1025,7 @@ extern "C" int ixtts_gpt_destroy(ixtts_gpt* h) {
   if (h->cap_stream) hipStreamDestroy(h->cap_stream);
   void* ptrs[] = {h->arena, h->stage, h->kc, h->vc, h->h, h->q, h->ff, h->att, h->part, h->logits, h->rowbuf, h->cur_len, h->gen_count,
                   h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->probs, h->scratch, h->beam_scores, h->hyp_score, h->hyp_worst, h->beam_src, h->hyp_len,
-                  h->n_hyp, h->beam_done, h->beam_forced_flag, h->beam_forced, h->hyp_tok, h->beam_cand_v, h->beam_cand_i, h->beam_cand_n,
+                  h->n_hyp, h->beam_done, h->beam_forced_flag, h->beam_forced, h->hyp_tok, h->beam_cand_v, h->beam_cand_i, h->beam_cand_n, h->beam_lcp,
                   h->rx, h->rxn, h->rq, h->ratt, h->rff, h->h2, h->wprx, h->mlp_part, h->mlp_ctr};
   for (void* p : ptrs)
     if (p) hipFree(p);

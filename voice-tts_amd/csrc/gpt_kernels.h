@@ -1240,29 +1240,32 @@ __device__ __forceinline__ void hist_add_aggregated(unsigned int* hist, unsigned
   }
 }
 
-// One radix-select pass's decision, by threads 0..255 together: the highest bin b whose suffix count S(b) = sum_{j >= b}
-// hist[j] reaches `rem` (bin 0 if none does); *prefix |= b << shift, *remaining = rem - S(b + 1).  (One thread walking the
-// 256 bins paid one dependent LDS read per bin: ~10 us per pass.)  Call with the whole 1024-thread workgroup, hist complete.
-__device__ __forceinline__ void radix_pick_bin(const unsigned int* hist, unsigned int* wtot, unsigned int* prefix, unsigned int* remaining, int shift) {
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const unsigned int rem = *remaining, pre = *prefix;
-  unsigned int x = t < 256 ? hist[t] : 0u;
-  unsigned int sfx = x;  // inclusive suffix sum within the wave
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned int y = __shfl_down(sfx, o, 64);
-    if (lane + o < 64) sfx += y;
-  }
-  if (t < 256 && lane == 0) wtot[w] = sfx;
-  __syncthreads();
-  if (t < 256) {
-    unsigned int above = 0u;  // bins of the higher waves
-    for (int ww = w + 1; ww < 4; ++ww) above += wtot[ww];
-    const unsigned int S = sfx + above;  // S(t)
-    const unsigned int Snext = S - x;    // S(t + 1)
-    if ((S >= rem && Snext < rem) || (t == 0 && S < rem)) {
-      *prefix = pre | ((unsigned int)t << shift);
-      *remaining = rem - Snext;
+// One radix-select pass's decision, by wave 0: the highest bin b whose suffix count S(b) = sum_{j >= b} hist[j] reaches `rem`
+// (bin 0 if none does); *prefix |= b << shift, *remaining = rem - S(b + 1).  Each lane takes four consecutive bins and the
+// lanes' totals go through one DPP scan.  (One thread walking the 256 bins paid one dependent LDS read per bin: ~10 us per
+// pass; 256 threads with shuffles and a hand-over between four waves: 0.6-0.8 us.)  Call with the whole workgroup, hist
+// complete; synchronised on return.
+__device__ __forceinline__ void radix_pick_bin(const unsigned int* hist, unsigned int* prefix, unsigned int* remaining, int shift) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const unsigned int rem = *remaining, pre = *prefix;
+    const uint4 h = *reinterpret_cast<const uint4*>(hist + 4 * lane);
+    const unsigned int mine = h.x + h.y + h.z + h.w;
+    const unsigned int incl = wave_scan_u32(mine);
+    const unsigned int total = (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
+    // suffix counts at this lane's bins, highest first
+    const unsigned int s3 = total - incl + h.w, s2 = s3 + h.z, s1 = s2 + h.y, s0 = s1 + h.x;
+    const unsigned int above = total - incl;  // S(4 * lane + 4)
+    int bin = -1;
+    unsigned int snext = 0u;
+    if (s3 >= rem && above < rem) { bin = 3; snext = above; }
+    else if (s2 >= rem && s3 < rem) { bin = 2; snext = s3; }
+    else if (s1 >= rem && s2 < rem) { bin = 1; snext = s2; }
+    else if (s0 >= rem && s1 < rem) { bin = 0; snext = s1; }
+    if (lane == 0 && s0 < rem) { bin = 0; snext = s1; }  // fewer than `rem` keys in all: the lowest bin
+    if (bin >= 0) {
+      *prefix = pre | ((unsigned int)(4 * lane + bin) << shift);
+      *remaining = rem - snext;
     }
   }
   __syncthreads();
@@ -1270,12 +1273,16 @@ __device__ __forceinline__ void radix_pick_bin(const unsigned int* hist, unsigne
 
 // ---- block helpers of the 1024-thread sampler kernels
 __device__ __forceinline__ float block_max_1024(float v, float* red) {
-  v = wave_max(v);
+  v = wave_max_dpp(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  float m = red[0];
-  for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+  float r[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r[i] = red[i];
+  float m = r[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) m = fmaxf(m, r[i]);
   return m;
 }
 __device__ __forceinline__ float block_sum_1024(float v, float* red) {
@@ -1283,8 +1290,12 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
+  float r[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r[i] = red[i];
   float s = 0.f;
-  for (int i = 0; i < 16; ++i) s += red[i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += r[i];
   return s;
 }
 
@@ -1388,8 +1399,207 @@ __device__ __forceinline__ void typical_filter_1024(float (&scores)[PT], int V, 
   __syncthreads();
 }
 
+#ifdef BEAM_DBG
+static __device__ unsigned long long g_beam_dbg[64];
+#define DBG_TS(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_beam_dbg[i] = wall_clock64(); } while (0)
+#define DBG_TSW(i, w) do { if (threadIdx.x == 64 * (w) && blockIdx.x == 0) g_beam_dbg[i] = wall_clock64(); } while (0)
+#else
+#define DBG_TS(i)
+#define DBG_TSW(i, w)
+#endif
 constexpr int SAMP_MAXK = 128;  // top_k supported on the device
 constexpr int SAMP_PT = 9;      // logits per thread (V <= 9216)
+constexpr int TOPK_POOL = 512;  // candidates at or above the k-th largest thread maximum
+
+struct TopkScratch {
+  alignas(16) unsigned int hist[256];
+  unsigned int sel_prefix, sel_remaining;
+  float pool_v[TOPK_POOL];
+  int pool_i[TOPK_POOL];
+  int pool_n;
+};
+
+// Key prefix of the k-th largest of the workgroup's keys (N per thread; element i of thread t counts when t + i*1024 < limit):
+// MSB radix select over the top 8*PASSES bits (4 passes: the exact key; fewer: its leading bits, the rest zero).  Whole
+// 1024-thread workgroup; synchronised on return.
+template <int N, int PASSES>
+__device__ __forceinline__ unsigned int radix_kth_1024(const unsigned int (&key)[N], int limit, int k, TopkScratch& sc) {
+  if (threadIdx.x == 0) {
+    sc.sel_prefix = 0u;
+    sc.sel_remaining = (unsigned int)k;
+  }
+  for (int pass = 0; pass < PASSES; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (threadIdx.x < 256) sc.hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned int prefix = sc.sel_prefix;
+    const unsigned int pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const bool in = (int)threadIdx.x + i * 1024 < limit && (key[i] & pmask) == prefix;
+      // the leading byte (sign + exponent) crowds into two or three bins: merge the wave's equal bins first; the later bytes
+      // spread over all 256 (merging them costs one round per distinct bin: 7 us in the second pass, measured)
+      if (pass == 0) hist_add_aggregated(sc.hist, (key[i] >> shift) & 0xffu, in);
+      else if (in) atomicAdd(&sc.hist[(key[i] >> shift) & 0xffu], 1u);
+    }
+    __syncthreads();
+    DBG_TS(35 + 2 * pass);
+    radix_pick_bin(sc.hist, &sc.sel_prefix, &sc.sel_remaining, shift);
+    DBG_TS(36 + 2 * pass);
+  }
+  return sc.sel_prefix;
+}
+
+// TopK for k <= SAMP_MAXK: the scores >= the k-th largest (ties with it kept, at most SAMP_MAXK of them), sorted descending
+// (value, then lower id first) into sort_v / sort_i [SAMP_MAXK] (-inf past the survivors); returns how many.  vals: this
+// thread's PT scores (index threadIdx.x + i*1024; -inf beyond V and for removed tokens, which never survive).
+// The k-th largest of the 1024 per-thread maxima is a lower bound of the k-th largest score (k distinct scores reach it), so
+// the scores at or above it -- here: at or above its leading 16 bits -- hold the whole top k plus a handful: two radix
+// passes over one key per thread instead of four over PT (36 wave-merged histogram rounds per step were most of the
+// sampling kernels' time), then an exact rank sort of that pool, one wave-wide ballot per element.
+template <int PT>
+__device__ __forceinline__ int topk_sorted_1024(const float (&vals)[PT], int V, int k, TopkScratch& sc, float* sort_v, int* sort_i) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  unsigned int key[PT], tmax[1] = {0u};
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    key[i] = f2key(vals[i]);
+    tmax[0] = max(tmax[0], key[i]);
+  }
+  if (t == 0) sc.pool_n = 0;
+  if (t < SAMP_MAXK) sort_v[t] = -INFINITY;
+  DBG_TS(30);
+  unsigned int thr = radix_kth_1024<1, 2>(tmax, 1024, k, sc);
+  DBG_TS(31);
+  auto collect = [&](int cap) {
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const bool hit = t + i * 1024 < V && key[i] >= thr && vals[i] > -INFINITY;
+      const unsigned long long m = __ballot(hit);
+      if (m) {  // one atomic per wave and register, the positions from the lane count (candidates are a few dozen in all)
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&sc.pool_n, (int)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+        if (hit && pos < cap) {
+          sc.pool_v[pos] = vals[i];
+          sc.pool_i[pos] = t + i * 1024;
+        }
+      }
+    }
+    __syncthreads();
+  };
+  collect(TOPK_POOL);
+  int np = sc.pool_n;
+  if (np > TOPK_POOL) {  // (workgroup-uniform) one thread holds many of the large scores: the exact select over every score instead
+    __syncthreads();
+    if (t == 0) sc.pool_n = 0;
+    thr = radix_kth_1024<PT, 4>(key, V, k, sc);
+    collect(SAMP_MAXK);
+    np = min(sc.pool_n, SAMP_MAXK);
+  }
+  if (np == 0) return 0;
+  // rank of pool element i = how many precede it: the wave's lanes hold the pool, one ballot per element and 64 of them
+  const int w_u = __builtin_amdgcn_readfirstlane(w);
+  if (np <= 64) {
+    const float pv = lane < np ? sc.pool_v[lane] : -INFINITY;
+    const int pi = lane < np ? sc.pool_i[lane] : 0x7fffffff;
+    for (int i = w_u; i < np; i += 16) {
+      const float mv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv), i));
+      const int mi = __builtin_amdgcn_readlane(pi, i);
+      const int rank = (int)__popcll(__ballot(pv > mv || (pv == mv && pi < mi)));
+      if (lane == 0) {
+        sort_v[rank] = mv;
+        sort_i[rank] = mi;
+      }
+    }
+  } else {
+    constexpr int NCH = TOPK_POOL / 64;
+    float pv[NCH];
+    int pi[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const bool in = lane + c * 64 < np;
+      pv[c] = in ? sc.pool_v[lane + c * 64] : -INFINITY;
+      pi[c] = in ? sc.pool_i[lane + c * 64] : 0x7fffffff;
+    }
+    for (int i = w_u; i < np; i += 16) {
+      const float mv = sc.pool_v[i];
+      const int mi = sc.pool_i[i];
+      int rank = 0;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) rank += (int)__popcll(__ballot(pv[c] > mv || (pv[c] == mv && pi[c] < mi)));
+      if (lane == 0 && rank < SAMP_MAXK) {
+        sort_v[rank] = mv;
+        sort_i[rank] = mi;
+      }
+    }
+  }
+  DBG_TS(33);
+  __syncthreads();
+  DBG_TS(34);
+#ifdef BEAM_DBG
+  if (threadIdx.x == 0 && blockIdx.x == 0) g_beam_dbg[40] = np;
+#endif
+  const float kth = sort_v[min(min(k, np), SAMP_MAXK) - 1];
+  return __popcll(__ballot(sort_v[lane] >= kth)) + __popcll(__ballot(sort_v[lane + 64] >= kth));
+}
+
+static_assert(SAMP_MAXK == 128, "topk_sorted_1024 counts the survivors as two 64-lane ballots");
+
+// One thread's running sums over an LDS array, in index order, eight loads in flight at a time (a dependent LDS read per
+// element was ~100 cycles each: 4-5 us of a sampling kernel).  x holds SAMP_MAXK floats; elements at or past n count as 0.
+__device__ __forceinline__ float seq_sum_lds(const float* x, int n) {
+  float z = 0.f;
+  for (int r0 = 0; r0 < n; r0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x[r0 + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) z += (r0 + u < n) ? v[u] : 0.f;
+  }
+  return z;
+}
+
+// TopPLogitsWarper over the n survivors in sort_v (descending), by wave 0 alone (call with threadIdx.x < 64): token r goes
+// while the probability mass of r and everything after it, summed from the last one backwards as the reference's ascending
+// cumsum does, stays <= 1 - top_p; the first min_keep always stay.  Returns how many stay; ev[SAMP_MAXK] is left holding the
+// softmax numerators exp(v - max) (0 past n), *Z_out their sum in index order.  The exponentials and quotients are computed
+// two per lane; the two running sums by every lane alike from LDS (wave-local hand-over: LDS serves one wave's accesses in
+// order).  On one thread, one dependent LDS read, one division and one branch per survivor, this was 2.7 us.
+__device__ __forceinline__ int topp_wave0(const float* sort_v, int n, float top_p, int min_keep, float* ev, float* qv, float* Z_out) {
+  const int lane = threadIdx.x;
+  const float mx = sort_v[0];
+  const float e0 = lane < n ? expf(sort_v[lane] - mx) : 0.f, e1 = lane + 64 < n ? expf(sort_v[lane + 64] - mx) : 0.f;
+  ev[lane] = e0;
+  ev[lane + 64] = e1;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  const float Z = seq_sum_lds(ev, n);
+  *Z_out = Z;
+  int keep = n;
+  if (top_p < 1.0f && n > 0) {
+    qv[lane] = e0 / Z;
+    qv[lane + 64] = e1 / Z;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    float tail = 0.f;
+    bool go = true;
+    for (int r0 = (n - 1) & ~7; r0 >= 0 && go; r0 -= 8) {
+      float q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = qv[r0 + u];
+#pragma unroll
+      for (int u = 7; u >= 0; --u) {
+        const int r = r0 + u;
+        if (go && r < n && r >= min_keep) {
+          tail += q[u];
+          if (tail <= 1.0f - top_p) keep = r;
+          else go = false;
+        }
+      }
+    }
+  }
+  return keep;
+}
 
 #ifdef IXTTS_ENGINE_TU  // non-template kernels: compiled into gpt_engine.hip only
 
@@ -1400,11 +1610,9 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerState s) {
   __shared__ float bv[16];
   __shared__ int bi[16];
   __shared__ int tok_s;
-  __shared__ unsigned int hist[256], wtot[4];
-  __shared__ unsigned int sel_prefix, sel_remaining;
-  __shared__ float cand_v[SAMP_MAXK], sort_v[SAMP_MAXK];
-  __shared__ int cand_i[SAMP_MAXK], sort_i[SAMP_MAXK];
-  __shared__ int cand_n;
+  __shared__ TopkScratch tk;
+  __shared__ float sort_v[SAMP_MAXK];
+  __shared__ int sort_i[SAMP_MAXK];
 
   const int slot = s.slot0 + blockIdx.x;
   // every load whose address is known at entry goes out first, unconditionally (clamped): logits, history bitmap, sampler
@@ -1474,7 +1682,6 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerState s) {
     bv[threadIdx.x >> 6] = best;
     bi[threadIdx.x >> 6] = besti;
   }
-  if (threadIdx.x == 0) cand_n = 0;
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; ++w)
@@ -1492,29 +1699,13 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerState s) {
     __shared__ TypicalScratch gs;
     __shared__ int pick_s;
     if (cfg.top_k > 0 && cfg.top_k < s.V) {
-      if (threadIdx.x == 0) {
-        sel_prefix = 0u;
-        sel_remaining = (unsigned int)cfg.top_k;
-      }
-      for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
-        __syncthreads();
-        const unsigned int prefix = sel_prefix;
-        const unsigned int pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+      unsigned int key[SAMP_PT];
 #pragma unroll
-        for (int i = 0; i < SAMP_PT; ++i) {
-          const int v = threadIdx.x + i * 1024;
-          const unsigned int key = f2key(vals[i]);
-          hist_add_aggregated(hist, (key >> shift) & 0xffu, v < s.V && (key & pmask) == prefix);
-        }
-        __syncthreads();
-        radix_pick_bin(hist, wtot, &sel_prefix, &sel_remaining, shift);
-      }
-      const unsigned int thr = sel_prefix;
+      for (int i = 0; i < SAMP_PT; ++i) key[i] = f2key(vals[i]);
+      const unsigned int thr = radix_kth_1024<SAMP_PT, 4>(key, s.V, cfg.top_k, tk);
 #pragma unroll
       for (int i = 0; i < SAMP_PT; ++i)
-        if (f2key(vals[i]) < thr) vals[i] = -INFINITY;
+        if (key[i] < thr) vals[i] = -INFINITY;
     }
     // softmax numerators over what is left
     float mx = -INFINITY;
@@ -1625,88 +1816,41 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerState s) {
     __syncthreads();
     if (threadIdx.x == 0 && pick_s >= 0) tok_s = pick_s;  // (target == total by rounding: the argmax already in tok_s)
   } else if (sampling) {
-    // ---- TopK: exact k-th largest key by 4-pass MSB radix select
+    // ---- TopK: the scores >= the k-th largest (ties kept), sorted descending (value, then lower id first)
     const int k = min(max(cfg.top_k, 1), SAMP_MAXK);
-    if (threadIdx.x == 0) {
-      sel_prefix = 0u;
-      sel_remaining = (unsigned int)k;
-    }
-    for (int pass = 0; pass < 4; ++pass) {
-      const int shift = 24 - 8 * pass;
-      if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
-      __syncthreads();
-      const unsigned int prefix = sel_prefix;
-      const unsigned int pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-#pragma unroll
-      for (int i = 0; i < SAMP_PT; ++i) {
-        const int v = threadIdx.x + i * 1024;
-        const unsigned int key = f2key(vals[i]);
-        hist_add_aggregated(hist, (key >> shift) & 0xffu, v < s.V && (key & pmask) == prefix);
-      }
-      __syncthreads();
-      radix_pick_bin(hist, wtot, &sel_prefix, &sel_remaining, shift);
-    }
-    const unsigned int thr = sel_prefix;  // key of the k-th largest score; ties with it are kept (scores < kth removed)
-#pragma unroll
-    for (int i = 0; i < SAMP_PT; ++i) {
-      const int v = threadIdx.x + i * 1024;
-      if (v < s.V && f2key(vals[i]) >= thr && vals[i] > -INFINITY) {
-        const int pos = atomicAdd(&cand_n, 1);
-        if (pos < SAMP_MAXK) {
-          cand_v[pos] = vals[i];
-          cand_i[pos] = v;
-        }
-      }
-    }
-    __syncthreads();
-    const int n = min(cand_n, SAMP_MAXK);
-    // ---- sort survivors descending (value, then lower id first) by rank counting
-    if (threadIdx.x < n) {
-      const float mv = cand_v[threadIdx.x];
-      const int mi = cand_i[threadIdx.x];
-      int rank = 0;
-      for (int j = 0; j < n; ++j) {
-        const float ov = cand_v[j];
-        const int oi = cand_i[j];
-        rank += (ov > mv || (ov == mv && oi < mi)) ? 1 : 0;
-      }
-      sort_v[rank] = mv;
-      sort_i[rank] = mi;
-    }
-    __syncthreads();
+    const int n = topk_sorted_1024<SAMP_PT>(vals, s.V, k, tk, sort_v, sort_i);
+    __shared__ float ev[SAMP_MAXK], qv[SAMP_MAXK];
     if (s.probs_out) {
       float* po = s.probs_out + (size_t)slot * s.V;
       for (int v = threadIdx.x; v < s.V; v += 1024) po[v] = 0.f;
+      __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x == 0 && n > 0) {
-      // ---- TopP over the survivors: drop token r when sum_{q >= r} p_q <= 1 - top_p (ascending cumsum), keep >= 1
-      const float mx = sort_v[0];
-      float Z = 0.f;
-      for (int r = 0; r < n; ++r) Z += expf(sort_v[r] - mx);
-      int keep = n;
-      if (cfg.top_p < 1.0f) {
-        float tail = 0.f;
-        for (int r = n - 1; r >= 1; --r) {
-          tail += expf(sort_v[r] - mx) / Z;
-          if (tail <= 1.0f - cfg.top_p) keep = r;
-          else break;
-        }
-      }
-      float Zk = 0.f;
-      for (int r = 0; r < keep; ++r) Zk += expf(sort_v[r] - mx);
-      // ---- multinomial(1) by inverse CDF
-      const float u = uniform01(cfg.seed, (unsigned int)slot, (unsigned int)s.gen_count[slot]) * Zk;
+    if (threadIdx.x < 64 && n > 0) {
+      // ---- TopP over the survivors (keep >= 1), then multinomial(1) by inverse CDF over the kept ones
+      float Z;
+      const int keep = topp_wave0(sort_v, n, cfg.top_p, 1, ev, qv, &Z);
+      const float Zk = seq_sum_lds(ev, keep);
+      const float u = uniform01(cfg.seed, (unsigned int)slot, (unsigned int)st_gen) * Zk;
       float c = 0.f;
       int pick = -1;
-      for (int r = 0; r < keep; ++r) {
-        const float pr = expf(sort_v[r] - mx);
-        if (s.probs_out) s.probs_out[(size_t)slot * s.V + sort_i[r]] = pr / Zk;
-        c += pr;
-        if (pick < 0 && u < c) pick = sort_i[r];
+      for (int r0 = 0; r0 < keep; r0 += 8) {
+        float pr[8];
+        int id[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          pr[q] = ev[r0 + q];
+          id[q] = sort_i[min(r0 + q, SAMP_MAXK - 1)];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (r0 + q < keep) {
+            if (s.probs_out && threadIdx.x == 0) s.probs_out[(size_t)slot * s.V + id[q]] = pr[q] / Zk;
+            c += pr[q];
+            if (pick < 0 && u < c) pick = id[q];
+          }
       }
       if (pick < 0) pick = sort_i[keep - 1];
-      tok_s = pick;
+      if (threadIdx.x == 0) tok_s = pick;
     }
   }
   __syncthreads();
