@@ -421,14 +421,15 @@ __global__ __launch_bounds__(1024) void beam_step_kernel(BeamArgs a) {
   DBG_TS(18);
 }
 
-constexpr int REORDER_CPT = 4;
+constexpr int REORDER_CPT = 4, REORDER_GX = 2;  // 2 x 1024 chunks = 256 rows of one head per pass
 
 // _reorder_cache: the generated rows [prompt_len, cur_len) of every layer's K and V follow `src` (the prompt rows are
 // identical across beams).  Slot j needs only rows [lo_j, cur_len) of slot src_j: below lo_j the two slots already hold the
 // same bytes (beam_step_kernel tracks, per pair of slots, how many leading rows were copied from a common ancestor --
 // beams re-converge every few steps, so the rows to move are the last few, not the whole history: 17 us per step on
-// average, 129 us at 1000 rows, when every row was moved).  grid (chunks, H, L*2), chunk 0 = the NEWEST rows; one
-// 16-byte chunk per thread, all beams read before any write.
+// average, 129 us at 1000 rows, when every row was moved).  grid (REORDER_GX, H, L*2), each workgroup striding over the
+// chunks from the NEWEST row backwards (the usual few rows are one pass; the grid no longer grows with the context
+// bucket); one 16-byte chunk per thread and step, all beams read before any write.
 __global__ __launch_bounds__(256) void beam_reorder_kv_kernel(void* kc, void* vc, const int* src, const int* lo, const int* prompt_len,
                                                                const int* cur_len, const int* done, int NB, int H, int smax,
                                                                size_t layer_stride_bytes, size_t slot_stride_bytes, int row_bytes, int every_row) {
@@ -443,22 +444,25 @@ __global__ __launch_bounds__(256) void beam_reorder_kv_kernel(void* kc, void* vc
     lo_min = min(lo_min, lj[j]);
   }
   const int cpr = row_bytes / 16;
-  if ((int)(blockIdx.x * REORDER_CPT * 256) >= (rows - lo_min) * cpr) return;
+  const int total = (rows - lo_min) * cpr;  // 16-byte chunks to look at, counted back from the newest row's last
+  if ((int)(blockIdx.x * REORDER_CPT * 256) >= total) return;
   const int layer = blockIdx.z >> 1, is_v = blockIdx.z & 1, hh = blockIdx.y;
   char* base0 = (char*)(is_v ? vc : kc) + layer * layer_stride_bytes + ((size_t)hh * smax + p0) * row_bytes;
+  for (int blk = blockIdx.x; blk * REORDER_CPT * 256 < total; blk += gridDim.x) {
 #pragma unroll
-  for (int c = 0; c < REORDER_CPT; ++c) {
-    const int back = (blockIdx.x * REORDER_CPT + c) * 256 + threadIdx.x;  // chunks counted back from the newest row's last
-    if (back >= (rows - lo_min) * cpr) break;
-    const int idx = rows * cpr - 1 - back;
-    const int row = idx / cpr;
-    char* base = base0 + (size_t)idx * 16;
-    uint4 v[BEAM_MAX];
+    for (int c = 0; c < REORDER_CPT; ++c) {
+      const int back = (blk * REORDER_CPT + c) * 256 + threadIdx.x;
+      if (back >= total) break;
+      const int idx = rows * cpr - 1 - back;
+      const int row = idx / cpr;
+      char* base = base0 + (size_t)idx * 16;
+      uint4 v[BEAM_MAX];
 #pragma unroll
-    for (int b = 0; b < BEAM_MAX; ++b) v[b] = *reinterpret_cast<const uint4*>(base + min(b, NB - 1) * slot_stride_bytes);
+      for (int b = 0; b < BEAM_MAX; ++b) v[b] = *reinterpret_cast<const uint4*>(base + min(b, NB - 1) * slot_stride_bytes);
 #pragma unroll
-    for (int j = 0; j < BEAM_MAX; ++j)
-      if (j < NB && row >= lj[j]) *reinterpret_cast<uint4*>(base + j * slot_stride_bytes) = sj[j] == 0 ? v[0] : sj[j] == 1 ? v[1] : sj[j] == 2 ? v[2] : v[3];
+      for (int j = 0; j < BEAM_MAX; ++j)
+        if (j < NB && row >= lj[j]) *reinterpret_cast<uint4*>(base + j * slot_stride_bytes) = sj[j] == 0 ? v[0] : sj[j] == 1 ? v[1] : sj[j] == 2 ? v[2] : v[3];
+    }
   }
 }
 
@@ -485,9 +489,7 @@ void launch_beam_step(ixtts_gpt* h, const SamplerState& s, hipStream_t st) {
   const int row_bytes = HD * (int)h->esize;
   const size_t slot_stride = (size_t)h->D * h->smax * h->esize;
   const size_t layer_stride = (size_t)h->slots * slot_stride;
-  // rows to move are bounded by the context bucket the graph is captured for (the host counts the steps it issues)
-  const int max_rows = h->attn_bucket < NBKT ? std::min(h->smax, attn_cover(h->attn_bucket)) : h->smax;
-  dim3 grid(ceil_div(max_rows * (row_bytes / 16), 256 * REORDER_CPT), h->H, h->L * 2);
+  dim3 grid(REORDER_GX, h->H, h->L * 2);
   hipLaunchKernelGGL(beam_reorder_kv_kernel, grid, dim3(256), 0, st, h->kc, h->vc, (const int*)h->beam_src, (const int*)(h->beam_lcp + BEAM_MAX * BEAM_MAX), (const int*)h->prompt_len,
                      (const int*)h->cur_len, (const int*)h->beam_done, h->num_beams, h->H, h->smax, layer_stride, slot_stride, row_bytes,
                      h->beam_every_row ? 1 : 0);

@@ -40,13 +40,15 @@ struct Dims<1280> {
   static constexpr int R1 = 2, R4 = 1, U_QKV = 2, U_OUT = 1, U_FC = 2, U_PR = 1, U_HEAD = 4;
   // waves per workgroup: 5 makes the 5120-row FC (4 rows/wave) and the 1280-row MLP-out (1 row/wave) exactly 256 equal
   // workgroups = one per CU (with 4, 320 workgroups put two on 64 of the CUs and those set the kernel time)
-  static constexpr int W_FC = 5, W_PR = 5;
+  // (twice the waves with half the rows each -- QKV 8 x 1 unit, FC 10 x 1 unit -- measured: 601.5 against 588.6 us per step
+  // at B=2, 670.9 against 666.6 at B=3)
+  static constexpr int W_QKV = 4, W_FC = 5, W_PR = 5;
   static constexpr bool XLDS = true;  // QKV / FC activations through LDS (see gemv_reg_kernel)
 };
 template <>
 struct Dims<128> {
   static constexpr int R1 = 4, R4 = 1, U_QKV = 1, U_OUT = 1, U_FC = 1, U_PR = 1, U_HEAD = 1;
-  static constexpr int W_FC = 4, W_PR = 4;
+  static constexpr int W_QKV = 4, W_FC = 4, W_PR = 4;
   static constexpr bool XLDS = true;
 };
 

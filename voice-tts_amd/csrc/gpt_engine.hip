@@ -85,13 +85,13 @@ static int gemv_qkv(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
         a.ln_b = A_F32(h->lo[l - 1].bpr);
         a.nsplit = h->slots;
         a.xout = (h->hc == h->h) ? h->h2 : h->h;
-        const int rc = launch_gemv<WT, KVT, D, DM::R1, DM::U_QKV, B, IN_LN_PART, EPI_QKV, 4, true>(a, st);
+        const int rc = launch_gemv<WT, KVT, D, DM::R1, DM::U_QKV, B, IN_LN_PART, EPI_QKV, DM::W_QKV, true>(a, st);
         h->hc = a.xout;
         return rc;
       }
     }
   }
-  return launch_gemv<WT, KVT, D, DM::R1, DM::U_QKV, B, IN_LN, EPI_QKV, 4, DM::XLDS>(a, st);
+  return launch_gemv<WT, KVT, D, DM::R1, DM::U_QKV, B, IN_LN, EPI_QKV, DM::W_QKV, DM::XLDS>(a, st);
 }
 
 template <typename WT, typename KVT, int D, int B>

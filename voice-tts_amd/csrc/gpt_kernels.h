@@ -1490,6 +1490,7 @@ __device__ __forceinline__ int topk_sorted_1024(const float (&vals)[PT], int V, 
     __syncthreads();
   };
   collect(TOPK_POOL);
+  DBG_TS(32);
   int np = sc.pool_n;
   if (np > TOPK_POOL) {  // (workgroup-uniform) one thread holds many of the large scores: the exact select over every score instead
     __syncthreads();
