@@ -217,7 +217,12 @@ def run_request(wl, hp, pr, texts, n_codes, mode, R=1, acc=None):
     tick = lambda: (torch.cuda.synchronize(), time.perf_counter())[1]
     t0 = tick()
     cl = wl.conds(pr)
+    if os.environ.get("IXTTS_BENCH_DETAIL"):
+        tc_ = tick()
     prompts = [hp.prepare_gpt_inputs(cl, t)[:2] for t in texts]
+    if os.environ.get("IXTTS_BENCH_DETAIL"):
+        tp_ = tick()
+        print(f"[detail] conditioning {1e3 * (tc_ - t0):.2f} ms, prepare_gpt_inputs {1e3 * (tp_ - tc_):.2f} ms", file=sys.stderr)
     if R > 1:
         many = hp.generate_many([(e, p, n_codes) for _ in range(R) for (e, p) in prompts], fixed_length=True, repetition_penalty=10.0)
     elif mode == "beam":  # served default (infer_v2.py:598-606): the beams of one segment occupy the slots, segments in turn

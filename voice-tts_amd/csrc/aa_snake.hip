@@ -11,36 +11,54 @@
 // live in LDS so every sin() is evaluated once, reads/writes of x/y are coalesced 4-byte
 // streams, and the down-filter reads LDS as conflict-free 8-byte pairs.
 //
-// Roofline: 8 B of HBM per element (read x, write y); 2 sin + ~40 FMA per element.
+// Roofline: 8 B of HBM per element (read x, write y); 2 sin^2 (12 instructions each) + 24 FMA per element.
 #include "common.h"
 
 namespace ixtts {
 
 constexpr int AA_TILE = 1024;    // outputs per workgroup
-constexpr int AA_THREADS = 256;  // 4 waves
-constexpr int AA_XH = 7;         // x halo each side
+constexpr int AA_THREADS = 256;  // 4 waves: four consecutive outputs per thread
+constexpr int AA_XH = 10;        // x halo each side (7 needed; 10 puts a thread's first input on a 16-byte LDS boundary)
 constexpr int AA_NX = AA_TILE + 2 * AA_XH;
-constexpr int AA_NS = 2 * AA_TILE + 12;  // s[2*t0-5 .. 2*(t0+TILE)+6]
+constexpr int AA_NS = 2 * AA_TILE + 16;  // ss[i] = s[2*t0 - 6 + i]
+static_assert(AA_TILE == 4 * AA_THREADS, "four outputs per thread");
+
+// sin(z)^2 for the Snake term.  sin^2 has period pi and is even, so one Cody-Waite reduction to r = z - n*pi in
+// [-pi/2, pi/2] (two fused steps, pi split hi + lo) and an odd minimax polynomial for sin(r) (degree 11) do it with no
+// quadrant logic: 12 instructions against ~40 for sinf(), 3e-7 absolute on sin^2 for |z| up to a few thousand -- the rounding
+// floor of squaring a float sine.  (The two sines were 70 % of this kernel's instructions.)
+__device__ __forceinline__ float sin_squared(float z) {
+  const float n = rintf(z * 0.318309886183790672f);
+  float r = fmaf(-n, 3.14159274101257324f, z);
+  r = fmaf(n, 8.74227765734758577e-08f, r);  // pi - float(pi) = -8.74e-8
+  const float w = r * r;
+  float p = -2.377017516153046e-08f;
+  p = fmaf(p, w, 2.7517328362591797e-06f);
+  p = fmaf(p, w, -0.00019840669119730592f);
+  p = fmaf(p, w, 0.008333329111337662f);
+  p = fmaf(p, w, -0.1666666716337204f);
+  p = fmaf(p, w, 1.0f);
+  const float sn = r * p;
+  return sn * sn;
+}
 
 template <bool FAST_SIN>
 __device__ __forceinline__ float snake(float u, float a, float inv_b) {
-  float sn;
   if constexpr (FAST_SIN) {
-    sn = __sinf(u * a);
+    const float sn = __sinf(u * a);
+    return u + inv_b * sn * sn;
   } else {
-    sn = sinf(u * a);
+    return u + inv_b * sin_squared(u * a);
   }
-  return u + inv_b * sn * sn;
 }
 
-// Shared device routine: also used by the conv kernels' fused prologue.
 template <bool FAST_SIN>
 __global__ __launch_bounds__(AA_THREADS) void aa_snake_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                const float* __restrict__ up12,
                                                                const float* __restrict__ down12,
                                                                const float* __restrict__ log_alpha,
                                                                const float* __restrict__ log_beta, int C, int T) {
-  __shared__ float xs[AA_NX];
+  __shared__ __attribute__((aligned(16))) float xs[AA_NX];
   __shared__ __attribute__((aligned(16))) float ss[AA_NS];
 
   const int row = blockIdx.y;  // b*C + c
@@ -58,7 +76,7 @@ __global__ __launch_bounds__(AA_THREADS) void aa_snake_kernel(const float* __res
   const float a = expf(log_alpha[c]);
   const float inv_b = 1.0f / (expf(log_beta[c]) + 1e-9f);
 
-  // stage x[t0-6 .. t0+TILE+6) with replicate clamping
+  // stage x[t0-10 .. t0+TILE+10) with replicate clamping
   for (int i = threadIdx.x; i < AA_NX; i += AA_THREADS) {
     int t = t0 - AA_XH + i;
     t = min(max(t, 0), T - 1);
@@ -66,45 +84,79 @@ __global__ __launch_bounds__(AA_THREADS) void aa_snake_kernel(const float* __res
   }
   __syncthreads();
 
-  // phase 1: one (even, odd) pair of up-sampled Snake values per thread-iteration.  Pair p <-> m = t0-3+p
-  // owns s[2m] -> ss[2p-1] and s[2m+1] -> ss[2p]; both share the 7 staged inputs x[m-3..m+3] (xs is already
-  // replicate-clamped, so no per-tap index clamps).  Replicate padding of s: m < 0 -> s[0], m > T-1 -> s[2T-1].
-  for (int pr = threadIdx.x; pr < AA_TILE + 7; pr += AA_THREADS) {
-    const int m = t0 - 3 + pr;
-    const int mc = min(max(m, 0), T - 1);
-    const float* xp = xs + (mc - 3) - (t0 - AA_XH);  // x[mc-3] .. x[mc+3]
-    float xw[7];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) xw[i] = xp[i];
+  // pair p <-> m = t0-3+p owns s[2m] -> ss[2p] and s[2m+1] -> ss[2p+1]; both share the 7 staged inputs x[m-3..m+3]
+  auto pair = [&](const float* xw, float& se, float& so) {
     float ue = 0.f, uo = 0.f;
 #pragma unroll
     for (int aa = 0; aa < 6; ++aa) {
       ue = fmaf(fu[11 - 2 * aa], xw[aa], ue);      // u[2m]   = 2 * sum_a f[11-2a] x[m-3+a]
       uo = fmaf(fu[10 - 2 * aa], xw[aa + 1], uo);  // u[2m+1] = 2 * sum_a f[10-2a] x[m-2+a]
     }
-    float se = snake<FAST_SIN>(2.0f * ue, a, inv_b);
-    float so = snake<FAST_SIN>(2.0f * uo, a, inv_b);
-    if (m < 0) so = se;
-    if (m > T - 1) se = so;
-    const int ie = 2 * pr - 1;
-    if (ie >= 0 && ie < AA_NS) ss[ie] = se;
-    if (ie + 1 < AA_NS) ss[ie + 1] = so;
+    se = snake<FAST_SIN>(2.0f * ue, a, inv_b);
+    so = snake<FAST_SIN>(2.0f * uo, a, inv_b);
+  };
+  const bool interior = t0 >= 3 && t0 + AA_TILE + 3 <= T - 1;  // every pair's m inside [0, T-1]: no replicate padding of s
+  if (interior) {
+    // phase 1: four consecutive pairs per thread from ten staged inputs (two 16-byte + one 8-byte LDS read, two 16-byte writes)
+    const int p0 = 4 * threadIdx.x;
+    float X[10];
+    *reinterpret_cast<float4*>(X) = *reinterpret_cast<const float4*>(xs + p0 + 4);  // x[m-3] of pair p0 sits at xs[p0 + 4]
+    *reinterpret_cast<float4*>(X + 4) = *reinterpret_cast<const float4*>(xs + p0 + 8);
+    *reinterpret_cast<float2*>(X + 8) = *reinterpret_cast<const float2*>(xs + p0 + 12);
+    float S[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pair(X + q, S[2 * q], S[2 * q + 1]);
+    *reinterpret_cast<float4*>(ss + 2 * p0) = *reinterpret_cast<const float4*>(S);
+    *reinterpret_cast<float4*>(ss + 2 * p0 + 4) = *reinterpret_cast<const float4*>(S + 4);
+    if (threadIdx.x < 7) {  // the seven pairs past the tile
+      const int pr = AA_TILE + threadIdx.x;
+      float xw[7], se, so;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) xw[i] = xs[pr + 4 + i];
+      pair(xw, se, so);
+      ss[2 * pr] = se;
+      ss[2 * pr + 1] = so;
+    }
+  } else {
+    // first / last tile of a row: replicate padding of s (m < 0 -> s[0], m > T-1 -> s[2T-1]), one pair per thread-iteration
+    for (int pr = threadIdx.x; pr < AA_TILE + 7; pr += AA_THREADS) {
+      const int m = t0 - 3 + pr;
+      const int mc = min(max(m, 0), T - 1);
+      const float* xp = xs + (mc - 3) - (t0 - AA_XH);  // x[mc-3] .. x[mc+3] (xs is already replicate-clamped)
+      float xw[7], se, so;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) xw[i] = xp[i];
+      pair(xw, se, so);
+      if (m < 0) so = se;
+      if (m > T - 1) se = so;
+      ss[2 * pr] = se;
+      ss[2 * pr + 1] = so;
+    }
   }
   __syncthreads();
 
-  // phase 2: y[t0+o] = sum_k fd[k]*ss[2*o+k]  (ss[i] <-> j = 2*t0-5+i)
-  for (int o = threadIdx.x; o < AA_TILE; o += AA_THREADS) {
-    int t = t0 + o;
-    if (t >= T) break;
-    const float2* sp = reinterpret_cast<const float2*>(ss + 2 * o);
-    float acc = 0.f;
+  // phase 2: y[t0+o] = sum_k fd[k] * s[2(t0+o)-5+k] = sum_k fd[k] * ss[2o+1+k]; four consecutive outputs per thread from
+  // twenty values (five 16-byte LDS reads)
+  {
+    const int o0 = 4 * threadIdx.x;
+    float S[20];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      float2 v = sp[k];
-      acc = fmaf(fd[2 * k], v.x, acc);
-      acc = fmaf(fd[2 * k + 1], v.y, acc);
+    for (int i = 0; i < 5; ++i) *reinterpret_cast<float4*>(S + 4 * i) = *reinterpret_cast<const float4*>(ss + 2 * o0 + 4 * i);
+    float acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[q] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc[q] = fmaf(fd[k], S[2 * q + 1 + k], acc[q]);
     }
-    yr[t] = acc;
+    const int t = t0 + o0;
+    if (t + 3 < T && ((reinterpret_cast<uintptr_t>(yr + t) & 15) == 0)) {
+      *reinterpret_cast<float4*>(yr + t) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (t + q < T) yr[t + q] = acc[q];
+    }
   }
 }
 

@@ -107,4 +107,20 @@ __device__ __forceinline__ unsigned int wave_scan_u32(unsigned int v) {
   return s;
 }
 
+// minimum of an int over the wave (DPP), to every lane
+__device__ __forceinline__ int wave_min_i32_dpp(int v) {
+  auto take = [](int x, auto ctrl, auto rm, auto bm) {
+    return __builtin_amdgcn_update_dpp(x, x, decltype(ctrl)::value, decltype(rm)::value, decltype(bm)::value, false);
+  };
+  using std::integral_constant;
+  int s = min(v, take(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{}));
+  s = min(s, take(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{}));
+  s = min(s, take(v, integral_constant<int, 0x113>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{}));
+  s = min(s, take(s, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xe>{}));
+  s = min(s, take(s, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xc>{}));
+  s = min(s, take(s, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, integral_constant<int, 0xf>{}));
+  s = min(s, take(s, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}, integral_constant<int, 0xf>{}));
+  return __builtin_amdgcn_readlane(s, 63);
+}
+
 }  // namespace ixtts

@@ -1669,15 +1669,12 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerState s) {
       }
     }
   }
-  // block argmax with lowest-index tie break (torch.argmax returns the first maximal element)
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const float ob = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(besti, o, 64);
-    if (ob > best || (ob == best && oi < besti)) {
-      best = ob;
-      besti = oi;
-    }
+  // block argmax with lowest-index tie break (torch.argmax returns the first maximal element): the wave's maximum, then the
+  // lowest index among the lanes that hold it (two DPP reductions; twelve ds_bpermute shuffles before)
+  {
+    const float wmax = wave_max_dpp(best);
+    besti = wave_min_i32_dpp(best == wmax ? besti : 0x7fffffff);
+    best = wmax;
   }
   if ((threadIdx.x & 63) == 0) {
     bv[threadIdx.x >> 6] = best;
@@ -1685,10 +1682,18 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerState s) {
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    float v16[16];
+    int i16[16];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      v16[w] = bv[w];
+      i16[w] = bi[w];
+    }
+#pragma unroll
     for (int w = 1; w < 16; ++w)
-      if (bv[w] > best || (bv[w] == best && bi[w] < besti)) {
-        best = bv[w];
-        besti = bi[w];
+      if (v16[w] > best || (v16[w] == best && i16[w] < besti)) {
+        best = v16[w];
+        besti = i16[w];
       }
     tok_s = besti;
   }
