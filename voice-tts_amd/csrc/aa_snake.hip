@@ -160,6 +160,150 @@ __global__ __launch_bounds__(AA_THREADS) void aa_snake_kernel(const float* __res
   }
 }
 
+// ---- the same activation writing the conv kernel's x planes (conv1d_x3.hip): y as three bf16 pieces per value, eight
+// consecutive channels of a time step in one 16-byte unit -> Xp[b][plane][C/8][T].  One workgroup = one channel octet x 256
+// outputs; wave r runs channel 8*o + r exactly as the fp32 kernel does (four consecutive outputs per lane), the 8 x 256 results
+// are transposed through LDS, and thread t splits and packs the eight channels of time step t: three 16-byte stores.
+constexpr int AP_TILE = 256;
+constexpr int AP_NX = AP_TILE + 2 * AA_XH;
+constexpr int AP_NS = 2 * AP_TILE + 16;
+
+__device__ __forceinline__ void split8_planes(const float (&v)[8], uint4& ph, uint4& pm, uint4& pl) {
+  unsigned int h[8], m[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = __float_as_uint(v[e]) + 0x8000u;  // round to nearest (ties away): truncated pieces would all err the same way
+    const float r = v[e] - __uint_as_float(h[e] & 0xffff0000u);
+    m[e] = __float_as_uint(r) + 0x8000u;
+    l[e] = __float_as_uint(r - __uint_as_float(m[e] & 0xffff0000u));  // exact: at most 8 significant bits are left
+  }
+  auto pk = [](unsigned int hi, unsigned int lo) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); };
+  ph = make_uint4(pk(h[1], h[0]), pk(h[3], h[2]), pk(h[5], h[4]), pk(h[7], h[6]));
+  pm = make_uint4(pk(m[1], m[0]), pk(m[3], m[2]), pk(m[5], m[4]), pk(m[7], m[6]));
+  pl = make_uint4(pk(l[1], l[0]), pk(l[3], l[2]), pk(l[5], l[4]), pk(l[7], l[6]));
+}
+
+template <bool FAST_SIN>
+__global__ __launch_bounds__(512) void aa_snake_planes_kernel(const float* __restrict__ x, uint4* __restrict__ xp, const float* __restrict__ up12,
+                                                              const float* __restrict__ down12, const float* __restrict__ log_alpha,
+                                                              const float* __restrict__ log_beta, int C, int T) {
+  __shared__ __attribute__((aligned(16))) float xs[8][AP_NX];
+  __shared__ __attribute__((aligned(16))) float ss[8][AP_NS];
+  __shared__ __attribute__((aligned(16))) float ys[8][AP_TILE];
+
+  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;  // wave r = channel r of the octet
+  const int o = blockIdx.y, b = blockIdx.z;
+  const int C8 = (C + 7) >> 3;
+  const int c = min(o * 8 + r, C - 1);  // (an octet past the tensor's channels: its rows are written as zeros below)
+  const bool live = o * 8 + r < C;
+  const int t0 = blockIdx.x * AP_TILE;
+  const float* xr = x + ((size_t)b * C + c) * T;
+
+  float fu[12], fd[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    fu[k] = up12[k];
+    fd[k] = down12[k];
+  }
+  const float a = expf(log_alpha[c]);
+  const float inv_b = 1.0f / (expf(log_beta[c]) + 1e-9f);
+
+  for (int i = lane; i < AP_NX; i += 64) {
+    int t = t0 - AA_XH + i;
+    t = min(max(t, 0), T - 1);
+    xs[r][i] = xr[t];
+  }
+  __syncthreads();
+  auto pair = [&](const float* xw, float& se, float& so) {
+    float ue = 0.f, uo = 0.f;
+#pragma unroll
+    for (int aa = 0; aa < 6; ++aa) {
+      ue = fmaf(fu[11 - 2 * aa], xw[aa], ue);
+      uo = fmaf(fu[10 - 2 * aa], xw[aa + 1], uo);
+    }
+    se = snake<FAST_SIN>(2.0f * ue, a, inv_b);
+    so = snake<FAST_SIN>(2.0f * uo, a, inv_b);
+  };
+  const bool interior = t0 >= 3 && t0 + AP_TILE + 3 <= T - 1;
+  if (interior) {
+    const int p0 = 4 * lane;
+    float X[10];
+    *reinterpret_cast<float4*>(X) = *reinterpret_cast<const float4*>(&xs[r][p0 + 4]);
+    *reinterpret_cast<float4*>(X + 4) = *reinterpret_cast<const float4*>(&xs[r][p0 + 8]);
+    *reinterpret_cast<float2*>(X + 8) = *reinterpret_cast<const float2*>(&xs[r][p0 + 12]);
+    float S[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pair(X + q, S[2 * q], S[2 * q + 1]);
+    *reinterpret_cast<float4*>(&ss[r][2 * p0]) = *reinterpret_cast<const float4*>(S);
+    *reinterpret_cast<float4*>(&ss[r][2 * p0 + 4]) = *reinterpret_cast<const float4*>(S + 4);
+    if (lane < 7) {
+      const int pr = AP_TILE + lane;
+      float xw[7], se, so;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) xw[i] = xs[r][pr + 4 + i];
+      pair(xw, se, so);
+      ss[r][2 * pr] = se;
+      ss[r][2 * pr + 1] = so;
+    }
+  } else {
+    for (int pr = lane; pr < AP_TILE + 7; pr += 64) {
+      const int m = t0 - 3 + pr;
+      const int mc = min(max(m, 0), T - 1);
+      const float* xq = &xs[r][(mc - 3) - (t0 - AA_XH)];
+      float xw[7], se, so;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) xw[i] = xq[i];
+      pair(xw, se, so);
+      if (m < 0) so = se;
+      if (m > T - 1) se = so;
+      ss[r][2 * pr] = se;
+      ss[r][2 * pr + 1] = so;
+    }
+  }
+  __syncthreads();
+  {
+    const int o0 = 4 * lane;
+    float S[20];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) *reinterpret_cast<float4*>(S + 4 * i) = *reinterpret_cast<const float4*>(&ss[r][2 * o0 + 4 * i]);
+    float acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[q] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc[q] = fmaf(fd[k], S[2 * q + 1 + k], acc[q]);
+      if (!live) acc[q] = 0.f;
+    }
+    *reinterpret_cast<float4*>(&ys[r][o0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+  __syncthreads();
+  if (threadIdx.x < AP_TILE && t0 + (int)threadIdx.x < T) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ys[e][threadIdx.x];
+    uint4 ph, pm, pl;
+    split8_planes(v, ph, pm, pl);
+    uint4* dst = xp + ((size_t)b * 3 * C8 + o) * T + t0 + threadIdx.x;
+    dst[0] = ph;
+    dst[(size_t)C8 * T] = pm;
+    dst[(size_t)2 * C8 * T] = pl;
+  }
+}
+
+int launch_aa_snake_planes(const float* x, void* xplanes, const float* up12, const float* down12, const float* la, const float* lb, int B, int C, int T,
+                           bool fast_sin, hipStream_t st) {
+  if (B * C == 0 || T == 0) return IXTTS_OK;
+  IX_ARG(B > 0 && C > 0 && T > 0, "aa_snake_planes: bad shape B=%d C=%d T=%d", B, C, T);
+  IX_ARG((C + 7) / 8 <= 65535 && B <= 65535, "aa_snake_planes: grid too large");
+  dim3 grid(ceil_div(T, AP_TILE), (C + 7) / 8, B);
+  if (fast_sin)
+    hipLaunchKernelGGL(aa_snake_planes_kernel<true>, grid, dim3(512), 0, st, x, reinterpret_cast<uint4*>(xplanes), up12, down12, la, lb, C, T);
+  else
+    hipLaunchKernelGGL(aa_snake_planes_kernel<false>, grid, dim3(512), 0, st, x, reinterpret_cast<uint4*>(xplanes), up12, down12, la, lb, C, T);
+  IX_HIP(hipGetLastError());
+  return IXTTS_OK;
+}
+
 int launch_aa_snake(const float* x, float* y, const float* up12, const float* down12, const float* la,
                     const float* lb, int B, int C, int T, bool fast_sin, hipStream_t st) {
   if (B * C == 0 || T == 0) return IXTTS_OK;

@@ -4,11 +4,14 @@
 // call site indextts/infer_v2.py:154-158,735.
 //
 // HBM layout
-//   weight arena (one hipMalloc, broadcastable): per conv  Wq[phase][tap][Cin_pad/8][2][Cout_pad][4] fp32
-//   + bias[Cout]; per activation log_alpha[C], log_beta[C]; the 12 filter taps.
+//   weight arena (one hipMalloc, broadcastable): per conv the weights as three bf16 planes
+//   Wx[phase*tap][Cin_pad/16][plane][2][Cout_pad][8] (conv1d_x3.hip; IXTTS_BV_CONV=f32: Wq[phase][tap][Cin_pad/8][2][Cout_pad][4]
+//   fp32 for the fp32-MFMA kernel of conv1d.hip) + bias[Cout]; per activation log_alpha[C], log_beta[C]; the 12 filter taps.
 //   activations: 11 buffers of 6144*F*B floats ([B][C][T] row-major, T contiguous):
 //     XS  previous stage output      X   stage input (after ups)
 //     per resblock branch j (3 of them): R_j running state / branch result, T1_j activation output, T2_j conv1 output
+//   conv inputs (x3 mode): 4 plane buffers [B][3][C/8][T][8] bf16 -- one per branch (written by the Snake passes) and one for
+//   the mel / the stage outputs the transposed convs read (written by the split pass)
 //
 // The three AMPBlock1 branches of a stage (k = 3, 7, 11) read the same input and only meet in the mean, so they run
 // CONCURRENTLY on three streams (forked after the up-sampling conv, joined in front of the k = 11 branch's last conv,
@@ -49,6 +52,9 @@ struct ixtts_bigvgan {
   static constexpr int NBUF = 11;
   float* buf[NBUF] = {};
   size_t buf_floats = 0;
+  bool x3 = true;      // convs on the bf16 matrix cores with three-way split operands (conv1d_x3.hip); IXTTS_BV_CONV=f32: conv1d.hip
+  void* pbuf[4] = {};  // x planes: one per resblock branch + one for the mel / stage outputs
+  size_t pbuf_bytes = 0;
   hipStream_t side[2] = {nullptr, nullptr};  // streams of the k = 3 / k = 7 branches (the caller's stream carries k = 11)
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   bool concurrent = true;                    // IXTTS_BV_STREAMS=1 keeps everything on the caller's stream
@@ -67,11 +73,12 @@ static void add_conv(ixtts_bigvgan* h, const std::string& name, int Cin, int Cou
   d.dil = dil;
   d.stride = stride;
   d.has_bias = bias;
-  d.Cin_pad = round_up(Cin, 8);
+  d.Cin_pad = round_up(Cin, h->x3 ? 16 : 8);
   d.Cout_pad = round_up(Cout, conv_tile_bm(Cout));
   d.pad = stride == 1 ? (K * dil - dil) / 2 : (K - stride) / 2;
   d.w_off = off;
-  off += (size_t)K * d.Cin_pad * d.Cout_pad;  // K taps in total (phases * taps-per-phase for transposed)
+  // K taps in total (phases * taps-per-phase for transposed); three bf16 planes = 6 bytes per weight in x3 mode
+  off += h->x3 ? (size_t)K * d.Cin_pad * d.Cout_pad * 3 / 2 : (size_t)K * d.Cin_pad * d.Cout_pad;
   off = (off + 3) & ~(size_t)3;
   d.b_off = off;
   off += round_up(Cout, 4);
@@ -99,6 +106,7 @@ extern "C" int ixtts_bigvgan_create(ixtts_bigvgan** out, const ixtts_bigvgan_cfg
   if (!h) return IXTTS_ERR_NOMEM;
   h->cfg = *cfg;
   if (const char* e = getenv("IXTTS_BV_STREAMS")) h->concurrent = strcmp(e, "1") != 0;
+  if (const char* e = getenv("IXTTS_BV_CONV")) h->x3 = strcmp(e, "f32") != 0;
   size_t off = 0;
   h->filt_off = off;
   off += 16;
@@ -179,6 +187,27 @@ static int ensure_workspace(ixtts_bigvgan* h, int B, int F) {
     }
   }
   h->buf_floats = need;
+  if (h->x3) {
+    // a plane buffer holds the largest conv input: C rounded up to 8 channels x T x 3 planes x 2 bytes
+    size_t pe = (size_t)round_up(h->cfg.num_mels, 8);
+    int c2 = h->cfg.upsample_initial_channel, up2 = 1;
+    if ((size_t)c2 > pe) pe = c2;
+    for (int i = 0; i < h->cfg.n_stages; ++i) {
+      c2 /= 2;
+      up2 *= h->cfg.upsample_rates[i];
+      if ((size_t)round_up(c2, 8) * up2 > pe) pe = (size_t)round_up(c2, 8) * up2;
+    }
+    const size_t pneed = pe * (size_t)F * B * 6;
+    for (int i = 0; i < 4; ++i) {
+      if (h->pbuf[i]) hipFree(h->pbuf[i]);
+      h->pbuf[i] = nullptr;
+      if (hipMalloc(&h->pbuf[i], pneed) != hipSuccess) {
+        set_error("bigvgan: plane workspace hipMalloc(%zu) failed", pneed);
+        return IXTTS_ERR_NOMEM;
+      }
+    }
+    h->pbuf_bytes = pneed;
+  }
   return IXTTS_OK;
 }
 
@@ -218,26 +247,48 @@ extern "C" int ixtts_bigvgan_set_tensor(ixtts_bigvgan* h, const char* name, cons
     d.w_set = true;
     return IXTTS_OK;
   }
-  std::vector<float> packed((size_t)d.K * d.Cin_pad * d.Cout_pad, 0.f);
-  // destination index of weight (tapslot, ci, co): Wq[tapslot][ci/8][ci%2][co][(ci%8)/2]   (conv1d.hip)
-  const int ngroups = d.Cin_pad / 8;
-  auto qidx = [&](int tapslot, int ci, int co) -> size_t {
-    const int g = ci / 8, r = ci % 8;
-    return ((((size_t)tapslot * ngroups + g) * 2 + (r & 1)) * d.Cout_pad + co) * 4 + (r >> 1);
+  // w(tapslot, ci, co) goes to
+  //   x3:  plane p of Wx[tapslot][ci/16][p][(ci%16)/8][co][ci%8] (bf16)                          (conv1d_x3.hip)
+  //   f32: Wq[tapslot][ci/8][ci%2][co][(ci%8)/2]                                                   (conv1d.hip)
+  const size_t nw = (size_t)d.K * d.Cin_pad * d.Cout_pad;
+  std::vector<float> packed(h->x3 ? nw * 3 / 2 : nw, 0.f);
+  uint16_t* planes = reinterpret_cast<uint16_t*>(packed.data());
+  const int ngroups = d.Cin_pad / 8, ng16 = d.Cin_pad / 16;
+  auto put = [&](int tapslot, int ci, int co, float v) {
+    if (!h->x3) {
+      const int g = ci / 8, r = ci % 8;
+      packed[((((size_t)tapslot * ngroups + g) * 2 + (r & 1)) * d.Cout_pad + co) * 4 + (r >> 1)] = v;
+      return;
+    }
+    // v = h + m + l exactly, each piece the remainder before it rounded to 8 significant bits (ties away)
+    uint32_t u, ru, lu;
+    memcpy(&u, &v, 4);
+    const uint32_t hu = (u + 0x8000u) & 0xffff0000u;
+    float hf, mf;
+    memcpy(&hf, &hu, 4);
+    const float r = v - hf;
+    memcpy(&ru, &r, 4);
+    const uint32_t mu = (ru + 0x8000u) & 0xffff0000u;
+    memcpy(&mf, &mu, 4);
+    const float lf = r - mf;
+    memcpy(&lu, &lf, 4);
+    const uint32_t piece[3] = {hu, mu, lu};
+    for (int pl = 0; pl < 3; ++pl)
+      planes[(((((size_t)tapslot * ng16 + ci / 16) * 3 + pl) * 2 + (ci % 16) / 8) * d.Cout_pad + co) * 8 + ci % 8] = (uint16_t)(piece[pl] >> 16);
   };
   if (d.stride == 1) {
     // Conv1d weight [Cout][Cin][K]
     IX_ARG(shape[0] == d.Cout && shape[1] == d.Cin && shape[2] == d.K, "bigvgan_set_tensor: %s expects [%d,%d,%d]", name, d.Cout, d.Cin, d.K);
     for (int co = 0; co < d.Cout; ++co)
       for (int ci = 0; ci < d.Cin; ++ci)
-        for (int k = 0; k < d.K; ++k) packed[qidx(k, ci, co)] = data[((size_t)co * d.Cin + ci) * d.K + k];
+        for (int k = 0; k < d.K; ++k) put(k, ci, co, data[((size_t)co * d.Cin + ci) * d.K + k]);
   } else {
     // ConvTranspose1d weight [Cin][Cout][K] -> tap slot = phase r * (K/stride) + j, k = r + stride*j
     IX_ARG(shape[0] == d.Cin && shape[1] == d.Cout && shape[2] == d.K, "bigvgan_set_tensor: %s expects [%d,%d,%d]", name, d.Cin, d.Cout, d.K);
     const int J = d.K / d.stride;
     for (int ci = 0; ci < d.Cin; ++ci)
       for (int co = 0; co < d.Cout; ++co)
-        for (int k = 0; k < d.K; ++k) packed[qidx((k % d.stride) * J + k / d.stride, ci, co)] = data[((size_t)ci * d.Cout + co) * d.K + k];
+        for (int k = 0; k < d.K; ++k) put((k % d.stride) * J + k / d.stride, ci, co, data[((size_t)ci * d.Cout + co) * d.K + k]);
   }
   IX_HIP(hipMemcpy(h->arena + d.w_off, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
   d.w_set = true;
@@ -296,6 +347,14 @@ static int run_act(ixtts_bigvgan* h, const std::string& name, const float* x, fl
   return launch_aa_snake(x, y, f, f, h->arena + a.a_off, h->arena + a.b_off, B, a.C, T, h->cfg.fast_sin != 0, st);
 }
 
+// the activation written as the next conv's x planes (x3 mode)
+static int run_act_planes(ixtts_bigvgan* h, const std::string& name, const float* x, void* xp, int B, int T, hipStream_t st) {
+  const ActDesc& a = h->acts.at(name);
+  const float* f = h->arena + h->filt_off;
+  return launch_aa_snake_planes(x, xp, f, f, h->arena + a.a_off, h->arena + a.b_off, B, a.C, T, h->cfg.fast_sin != 0, st);
+}
+
+// x: [B][Cin][Tin] fp32, or (x3 mode) the planes of that tensor
 static int run_conv(ixtts_bigvgan* h, const std::string& name, const float* x, float* y, const float* res,
                     const float* accum, int div3, int B, int Tin, hipStream_t st, const float* accum2 = nullptr) {
   const ConvDesc& d = h->convs.at(name);
@@ -337,13 +396,14 @@ static int run_conv(ixtts_bigvgan* h, const std::string& name, const float* x, f
     p.nphase = d.stride;
   }
   static const bool timing = getenv("IXTTS_BV_TIMING") != nullptr;  // developer table: per conv shape, time and TFLOP/s
-  if (!timing) return launch_conv1d(p, st);
+  auto launch = [&]() { return h->x3 ? launch_conv1d_x3(p, st) : launch_conv1d(p, st); };
+  if (!timing) return launch();
   static std::map<std::string, std::pair<double, double>> table;  // shape -> (us, flops)
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   hipEventRecord(e0, st);
-  const int rc = launch_conv1d(p, st);
+  const int rc = launch();
   hipEventRecord(e1, st);
   hipEventSynchronize(e1);
   float ms = 0.f;
@@ -387,32 +447,45 @@ extern "C" int ixtts_bigvgan_forward(ixtts_bigvgan* h, const float* mel, int B, 
     }
     IX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   }
-  IX_TRY(run_conv(h, "conv_pre", mel, XS, nullptr, nullptr, 0, B, F, st));
+  // conv input of a resblock conv: the Snake pass writes it -- fp32 rows for conv1d.hip, the x planes for conv1d_x3.hip
+  auto act_to = [&](const std::string& name, const float* src, float* f32dst, void* planes, int T_, hipStream_t s_) {
+    return h->x3 ? run_act_planes(h, name, src, planes, B, T_, s_) : run_act(h, name, src, f32dst, B, T_, s_);
+  };
+  // conv input that no Snake pass produces (the mel, a stage output): split pass in x3 mode
+  auto conv_in = [&](const float* src, int C_, int T_) -> const float* {
+    if (!h->x3) return src;
+    launch_split_planes(src, h->pbuf[3], B, C_, T_, st);
+    return reinterpret_cast<const float*>(h->pbuf[3]);
+  };
+  IX_TRY(run_conv(h, "conv_pre", conv_in(mel, c.num_mels, F), XS, nullptr, nullptr, 0, B, F, st));
   int T = F;
+  int ch = c.upsample_initial_channel;
   for (int i = 0; i < c.n_stages; ++i) {
-    IX_TRY(run_conv(h, "ups." + std::to_string(i) + ".0", XS, X, nullptr, nullptr, 0, B, T, st));
+    IX_TRY(run_conv(h, "ups." + std::to_string(i) + ".0", conv_in(XS, ch, T), X, nullptr, nullptr, 0, B, T, st));
     T *= c.upsample_rates[i];
+    ch /= 2;
     if (conc) IX_HIP(hipEventRecord(h->ev_fork, st));
     // branch j works in (R_j, T1_j, T2_j); the longest one (the last kernel size) stays on the caller's stream and forms the mean
     for (int j = 0; j < c.n_resblock_kernels; ++j) {
       const bool last = j == c.n_resblock_kernels - 1;
       hipStream_t bs = (conc && !last) ? h->side[j] : st;
       float *Rj = h->buf[2 + 3 * j], *T1j = h->buf[3 + 3 * j], *T2j = h->buf[4 + 3 * j];
+      const float* Aj = h->x3 ? reinterpret_cast<const float*>(h->pbuf[j]) : T1j;  // what the convs of this branch read
       if (conc && !last) IX_HIP(hipStreamWaitEvent(bs, h->ev_fork, 0));
       std::string p = "resblocks." + std::to_string(i * c.n_resblock_kernels + j);
       const float* cur = X;
       for (int m = 0; m < 3; ++m) {
-        IX_TRY(run_act(h, p + ".activations." + std::to_string(2 * m) + ".act", cur, T1j, B, T, bs));
-        IX_TRY(run_conv(h, p + ".convs1." + std::to_string(m), T1j, T2j, nullptr, nullptr, 0, B, T, bs));
-        IX_TRY(run_act(h, p + ".activations." + std::to_string(2 * m + 1) + ".act", T2j, T1j, B, T, bs));
+        IX_TRY(act_to(p + ".activations." + std::to_string(2 * m) + ".act", cur, T1j, h->pbuf[j], T, bs));
+        IX_TRY(run_conv(h, p + ".convs1." + std::to_string(m), Aj, T2j, nullptr, nullptr, 0, B, T, bs));
+        IX_TRY(act_to(p + ".activations." + std::to_string(2 * m + 1) + ".act", T2j, T1j, h->pbuf[j], T, bs));
         if (m < 2 || !last) {
-          IX_TRY(run_conv(h, p + ".convs2." + std::to_string(m), T1j, Rj, cur, nullptr, 0, B, T, bs));
+          IX_TRY(run_conv(h, p + ".convs2." + std::to_string(m), Aj, Rj, cur, nullptr, 0, B, T, bs));
           cur = Rj;
         } else {
           // xs = r0 ; xs += r1 ; x = (xs + r2) / 3      (bigvgan.py:369-375)
           if (conc)
             for (int k = 0; k < 2; ++k) IX_HIP(hipStreamWaitEvent(st, h->ev_join[k], 0));
-          IX_TRY(run_conv(h, p + ".convs2." + std::to_string(m), T1j, XS, cur, h->buf[2], 1, B, T, st, h->buf[5]));
+          IX_TRY(run_conv(h, p + ".convs2." + std::to_string(m), Aj, XS, cur, h->buf[2], 1, B, T, st, h->buf[5]));
         }
       }
       if (conc && !last) IX_HIP(hipEventRecord(h->ev_join[j], bs));
@@ -445,6 +518,8 @@ extern "C" int ixtts_bigvgan_destroy(ixtts_bigvgan* h) {
   if (h->arena) hipFree(h->arena);
   for (int i = 0; i < ixtts_bigvgan::NBUF; ++i)
     if (h->buf[i]) hipFree(h->buf[i]);
+  for (int i = 0; i < 4; ++i)
+    if (h->pbuf[i]) hipFree(h->pbuf[i]);
   for (int k = 0; k < 2; ++k) {
     if (h->side[k]) hipStreamDestroy(h->side[k]);
     if (h->ev_join[k]) hipEventDestroy(h->ev_join[k]);
