@@ -74,7 +74,7 @@ static void add_conv(ixtts_bigvgan* h, const std::string& name, int Cin, int Cou
   d.stride = stride;
   d.has_bias = bias;
   d.Cin_pad = round_up(Cin, h->x3 ? 16 : 8);
-  d.Cout_pad = round_up(Cout, conv_tile_bm(Cout));
+  d.Cout_pad = h->x3 ? conv_x3_cout_pad(Cout) : round_up(Cout, conv_tile_bm(Cout));
   d.pad = stride == 1 ? (K * dil - dil) / 2 : (K - stride) / 2;
   d.w_off = off;
   // K taps in total (phases * taps-per-phase for transposed); three bf16 planes = 6 bytes per weight in x3 mode

@@ -25,6 +25,7 @@ struct ConvParams {
 int launch_conv1d(const ConvParams& p, hipStream_t st);
 // the same operator with x and the weights as three bf16 planes each (conv1d_x3.hip): p.x = x planes, p.wp = weight planes
 int launch_conv1d_x3(const ConvParams& p, hipStream_t st);
+int conv_x3_cout_pad(int Cout);
 int launch_split_planes(const float* x, void* xplanes, int B, int C, int T, hipStream_t st);
 int launch_conv_post(const float* x, const float* w, const float* bias, float* y, int B, int C, int T, hipStream_t st);
 int conv_tile_bm(int Cout);

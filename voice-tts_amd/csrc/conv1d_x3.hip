@@ -14,6 +14,8 @@
 //             the split pass): the B operand of a lane is ONE unit, the x tile of a chunk is copied by 16-byte LDS-DMA
 //   weights   Wx[phase*tap][Cin/16][plane 3][k-half 2][Cout_pad] 16-byte units (eight consecutive input channels of one output
 //             channel), streamed from L2 one tap ahead as in conv1d.hip.
+#include <algorithm>
+
 #include "conv.h"
 
 namespace ixtts {
@@ -107,39 +109,34 @@ __global__ __launch_bounds__(256, 2) void conv1d_x3_kernel(ConvParams p) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) bq[pl][j] = xrow[(pl * 4 + gg * 2) * XW + j * 32];
   };
+  const bool wave_live = m0 + wm * (32 * MT) < p.Cout;
   uint4 a_cur[2][3][MT], a_nxt[2][3][MT];
-  uint4 bcarry[3][NT];  // B fragments of the next tap's first group, read under the current tap's last group
+  // B fragments: group gg of a tap lives in bq[gg]; while group 0 runs, group 1 is read into bq[1]; while group 1 runs, group 0
+  // of the NEXT tap is read into bq[0] (the LDS reads of a group always go out one group of MFMAs ahead)
+  uint4 bq[2][3][NT];
   auto run_tap = [&](const uint4* Xc, int g, int tap) {
     const bool last_tap = tap + 1 >= p.ntap;
     load_a(a_nxt, last_tap ? min(g + 1, nchunks - 1) : g, last_tap ? 0 : tap + 1);
     const int xoff = (p.dil >= 0) ? tap * adil : (p.ntap - 1 - tap) * adil;
-    const int tap_n = last_tap ? tap : tap + 1;
+    const int tap_n = last_tap ? tap : tap + 1;  // (past the last tap of a chunk the prefetched fragments are not used)
     const int xoff_n = (p.dil >= 0) ? tap_n * adil : (p.ntap - 1 - tap_n) * adil;
     const uint4* xrow = Xc + lh * XW + wn * (32 * NT) + l31 + xoff;
     const uint4* xrow_n = Xc + lh * XW + wn * (32 * NT) + l31 + xoff_n;
-    uint4 bq[2][3][NT];
-    if (tap == 0) {
-      load_b(bq[0], xrow, 0);
-    } else {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bq[0][pl][j] = bcarry[pl][j];
-    }
+    if (tap == 0) load_b(bq[0], xrow, 0);
 #pragma unroll
     for (int gg = 0; gg < 2; ++gg) {
-      if (gg + 1 < 2) load_b(bq[(gg + 1) & 1], xrow, gg + 1);
-      else load_b(bcarry, xrow_n, 0);
+      if (gg == 0) load_b(bq[1], xrow, 1);
+      else load_b(bq[0], xrow_n, 0);
       __builtin_amdgcn_sched_barrier(0);  // the next group's LDS reads go out before this group's MFMAs
-      if (g * 2 + gg < ng) {              // (workgroup-uniform) a ragged last chunk has one group
+      if (g * 2 + gg < ng && wave_live) {  // (wave-uniform) a ragged last chunk has one group; a wave whose rows are all padding idles
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             const cx_bf16x8 ah = __builtin_bit_cast(cx_bf16x8, a_cur[gg][0][i]), am = __builtin_bit_cast(cx_bf16x8, a_cur[gg][1][i]),
                             al = __builtin_bit_cast(cx_bf16x8, a_cur[gg][2][i]);
-            const cx_bf16x8 bh = __builtin_bit_cast(cx_bf16x8, bq[gg & 1][0][j]), bm = __builtin_bit_cast(cx_bf16x8, bq[gg & 1][1][j]),
-                            bl = __builtin_bit_cast(cx_bf16x8, bq[gg & 1][2][j]);
+            const cx_bf16x8 bh = __builtin_bit_cast(cx_bf16x8, bq[gg][0][j]), bm = __builtin_bit_cast(cx_bf16x8, bq[gg][1][j]),
+                            bl = __builtin_bit_cast(cx_bf16x8, bq[gg][2][j]);
             // smallest partial products first
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
@@ -240,25 +237,37 @@ static int launch_x3_cfg(const ConvParams& p0, hipStream_t st) {
   return IXTTS_OK;
 }
 
-static double x3_tile_score(const ConvParams& p, int BM, int BN, double pref) {
+// Cout padding of the packed weights: a whole number of the row tiles that may be used for this Cout
+int conv_x3_cout_pad(int Cout) { return Cout <= 32 ? 32 : Cout <= 64 ? 64 : (Cout + 127) / 128 * 128; }
+
+// Workgroups of one launch run in rounds over the CUs' slots (co-resident workgroups of a CU share its matrix pipe); a
+// workgroup's LDS (two x-tile buffers) decides how many fit a CU.  Score = useful fraction of the MFMA work of those rounds
+// (tile quantisation in both directions) x a mild preference for the bigger tile (fewer L2 bytes per flop).
+static double x3_tile_score(const ConvParams& p, int BM, int BN, int max_occ, double pref) {
+  const int adil = p.dil < 0 ? -p.dil : p.dil;
+  const size_t smem = (size_t)2 * 12 * (BN + (p.ntap - 1) * adil) * 16;
+  const int occ = std::max(1, std::min(max_occ, (int)((160 * 1024) / (smem + 512))));
   const double wgs = (double)ceil_div(p.Cout, BM) * ceil_div(p.Nq, BN) * p.B * p.nphase;
-  const double rounds = (double)(((long long)wgs + 511) / 512);  // two workgroups per CU
-  return wgs / (rounds * 512.0) * pref;
+  const double slots = 256.0 * occ;
+  const double rounds = (double)(((long long)wgs + (long long)slots - 1) / (long long)slots);
+  const double useful = (double)p.Cout * p.Nq * p.B * p.nphase / (wgs * BM * BN);
+  return useful * wgs / (rounds * slots) * pref;
 }
 
-// p.x = the x planes, p.wp = the weight planes (see the header); everything else as launch_conv1d
+// p.x = the x planes, p.wp = the weight planes (see the header); everything else as launch_conv1d.
+// Wave layouts: every wave owns 32 output channels (one A fragment set per 16 input channels) and as many columns as the tile
+// allows -- 128 in the 128-row tile (4 x 1 waves), 64 in the 64-row tile (2 x 2): the A operands come from L2, and L2 -> CU
+// bandwidth is what bounds this loop (the spike loses a third of its rate when they are added), so a wave re-uses each of them
+// for as many column tiles as its registers hold.
 int launch_conv1d_x3(const ConvParams& p, hipStream_t st) {
   IX_ARG(p.Cin_pad % 16 == 0, "conv_x3: Cin_pad %d not a multiple of 16", p.Cin_pad);
-  switch (conv_tile_bm(p.Cout)) {
-    case 32: return launch_x3_cfg<1, 1, 1, 4>(p, st);  // 32 x 128
-    case 64: return launch_x3_cfg<2, 1, 1, 4>(p, st);  // 64 x 128
-    case 96: return launch_x3_cfg<3, 1, 1, 4>(p, st);  // 96 x 128
-    default: {
-      const double s128 = x3_tile_score(p, 128, 128, 1.00), s64x128 = x3_tile_score(p, 64, 128, 0.93);
-      if (s128 >= s64x128) return launch_x3_cfg<2, 2, 2, 2>(p, st);  // 128 x 128
-      return launch_x3_cfg<1, 2, 2, 2>(p, st);                        // 64 x 128
-    }
-  }
+  if (p.Cout_pad == 32) return launch_x3_cfg<1, 1, 1, 4>(p, st);  // 32 x 128
+  if (p.Cout_pad == 64) return launch_x3_cfg<1, 2, 2, 2>(p, st);  // 64 x 128
+  // (few taps per x tile -- the polyphase transposed convs have 2 to 4 -- and the tile copy weighs as much as the weights: the
+  // 128-row tile halves both per flop: 252 against 369 us for the 768 -> 384 up-sampling conv)
+  const double s128 = x3_tile_score(p, 128, 128, 2, 1.00), s64 = x3_tile_score(p, 64, 128, 3, p.ntap >= 3 ? 0.93 : 0.65);
+  if (s128 >= s64) return launch_x3_cfg<1, 4, 4, 1>(p, st);        // 128 x 128
+  return launch_x3_cfg<1, 2, 2, 2>(p, st);                          // 64 x 128
 }
 
 // ------------------------------------------------------------------------------------
