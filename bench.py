@@ -36,7 +36,18 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402,F401
 import torch  # noqa: E402
 
-PEAK_HBM, PEAK_F32 = 8000.0, 157.3  # GB/s, TFLOP/s (MI355X_MICROARCH.md)
+PEAK_HBM, PEAK_F32, PEAK_BF16 = 8000.0, 157.3, 2500.0  # GB/s, TFLOP/s fp32 MFMA, TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def conv_roofline(tflops):
+    """Roofline block of the BigVGAN convs.  Default build: fp32-accurate products as six bf16 MFMAs of three-way split operands
+    (csrc/conv1d_x3.hip) -- the bound is the dense bf16 MFMA peak / 6 per fp32-equivalent flop; IXTTS_BV_CONV=f32: the fp32 MFMA peak.
+    `tflops` counts 2 * Cout * Cin * k * T per conv either way (fp32-equivalent), so the fp32-MFMA figure stays comparable."""
+    x3 = os.environ.get("IXTTS_BV_CONV", "x3") != "f32"
+    peak = PEAK_BF16 / 6 if x3 else PEAK_F32
+    return {"bound": "mfma", "achieved": round(tflops, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tflops / peak, 3),
+            "arithmetic": "fp32-equivalent flops; six bf16 MFMA partial products per fp32 product, fp32 accumulate" if x3 else "fp32 MFMA",
+            "fp32_mfma_peak": PEAK_F32, "frac_of_fp32_mfma_peak": round(tflops / PEAK_F32, 3)}
 
 
 def host_cores():
@@ -122,8 +133,7 @@ def bigvgan_microbench(WR, dev, model=None):
     return {"metric": "bigvgan_ms_per_1000_frames", "value": round(ms, 3), "unit": "ms", "n_gpus": 1, "steps": 100, "warmup": 20,
             "higher_is_better": False, "dtype": "f32", "data": "synthetic", "audio_seconds_per_second": round(256 * F / 22050 / (ms * 1e-3), 1),
             "config": {"workload": "BigVGAN-only: 1000-frame random mel -> 256000 samples (11.61 s)"},
-            "roofline": {"bound": "mfma", "achieved": round(fl / ms / 1e9, 1), "peak": PEAK_F32, "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / PEAK_F32, 3),
-                         "flops": fl, "hbm_GBps_algorithmic": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "hbm_peak_GBps": PEAK_HBM}}
+            "roofline": dict(conv_roofline(fl / ms / 1e9), flops=fl, hbm_GBps_algorithmic=round(alg_bytes / (ms * 1e-3) / 1e9, 1), hbm_peak_GBps=PEAK_HBM)}
 
 
 def decode_step_by_batch(hp, P, batches, n_steps=256):
@@ -442,8 +452,7 @@ def main():
     stage_roof = None
     if rank == 0 and not args.no_roofline and not mixed:
         bv_tf = hp.bigvgan.flops(1, frames) * n_seg * R / (stage_ms["bigvgan"] / args.steps * 1e-3) / 1e12
-        stage_roof = {"bigvgan": {"bound": "mfma", "achieved": round(bv_tf, 1), "peak": PEAK_F32, "unit": "TFLOP/s", "frac": round(bv_tf / PEAK_F32, 3),
-                                  "flops_per_segment": hp.bigvgan.flops(1, frames)}}
+        stage_roof = {"bigvgan": dict(conv_roofline(bv_tf), flops_per_segment=hp.bigvgan.flops(1, frames))}
         if use_s2mel:
             from voice_tts_amd.s2mel import attn_full
 
@@ -470,7 +479,8 @@ def main():
         log("extra: BigVGAN config-5 microbench")
         mb = bigvgan_microbench(WR, dev, hp.bigvgan)
         extra["bigvgan_config5"] = {"ms_per_1000_frames": mb["value"], "audio_seconds_per_second": mb["audio_seconds_per_second"],
-                                    "TFLOPs": mb["roofline"]["achieved"], "frac_fp32_mfma_peak": mb["roofline"]["frac"]}
+                                    "TFLOPs": mb["roofline"]["achieved"], "frac": mb["roofline"]["frac"], "peak": mb["roofline"]["peak"],
+                                    "frac_fp32_mfma_peak": mb["roofline"]["frac_of_fp32_mfma_peak"]}
         one_audio = audio_seconds([n_codes] * n_seg)
         for name, dtype, mode, mb_ in (("beam3_bf16", "bf16", "beam", 3), ("greedy_fp32", "f32", "greedy", min(max(2, n_seg), engine_max))):
             log(f"extra: {name} request")
@@ -606,7 +616,7 @@ def main():
                 "segments": n_seg if not mixed else n_segs, "text_tokens_per_segment": n_tok if not mixed else "50-400 chars / ceil(len/120)",
                 "codes_per_segment": n_codes if not mixed else "11 per token", "mel_frames_per_segment": frames if not mixed else "floor(1.72 codes)",
                 "audio_seconds_per_step": round(total_audio / args.steps, 3), "parallelism": f"request-per-GPU x{world}, RCCL weight broadcast at load",
-                "gpt_precision": f"{args.dtype} weights+KV, fp32 accumulate", "bigvgan_precision": "fp32 (fp32 MFMA)",
+                "gpt_precision": f"{args.dtype} weights+KV, fp32 accumulate", "bigvgan_precision": "fp32 tensors; conv products as six bf16 MFMA partial products of exactly split operands, fp32 accumulate" if os.environ.get("IXTTS_BV_CONV", "x3") != "f32" else "fp32 (fp32 MFMA)",
                 "s2mel": "torch fp32 glue + HIP attention / row kernels in the timed region" if use_s2mel else "excluded",
                 "conditioning": "torch fp32 glue in the timed region (inside gpt_gen)" if use_cond else "excluded",
             },

@@ -2,6 +2,9 @@
 
 Tolerance: fp32 waveform, max-abs <= 1e-3 (BASELINE.json north_star) -- asserted 20x tighter
 (5e-5) on the tiny twin and 1e-4 on production-width slices, values being O(0.1..1).
+
+The default build runs the convs as six bf16 MFMA partial products of exactly split fp32 operands (csrc/conv1d_x3.hip); every
+test here exercises that path.  `test_conv_arithmetic_modes_agree` also builds the fp32-MFMA kernel (IXTTS_BV_CONV=f32).
 """
 import numpy as np
 import pytest
@@ -126,3 +129,24 @@ def test_fast_sin_mode_within_north_star_tolerance(dev):
     assert (exact - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
     err = (fast - ref).abs().max().item()
     assert err <= 1e-4, err
+
+
+def test_conv_arithmetic_modes_agree(dev, monkeypatch):
+    """conv1d_x3.hip (x = h + m + l in bf16, six partial products, fp32 accumulate) against conv1d.hip (fp32 MFMA) on a
+    production-width 2-stage twin: both within 1e-4 of the oracle, and of each other (two summation orders of the same products)."""
+    from oracle import vocoder as OV
+    import voice_tts_amd.weights as WR
+    from voice_tts_amd.bigvgan import BigVGAN
+
+    cfg = dict(WR.BIGVGAN_CFG)
+    cfg.update(upsample_initial_channel=768, upsample_rates=(4, 2), upsample_kernel_sizes=(8, 4))
+    W = WR.make_bigvgan_weights(cfg, seed=78)
+    mel = (torch.randn(2, 80, 45, generator=torch.Generator().manual_seed(10)) * 2 - 4).clamp(-11.5, 2)
+    ref = OV.bigvgan_forward(mel, W, cfg)
+    x3 = BigVGAN(cfg, max_frames=64, device=dev).load_state_dict(W)(mel.to(dev)).cpu()
+    monkeypatch.setenv("IXTTS_BV_CONV", "f32")
+    f32 = BigVGAN(cfg, max_frames=64, device=dev).load_state_dict(W)(mel.to(dev)).cpu()
+    scale = max(1.0, ref.abs().max().item())
+    assert (x3 - ref).abs().max().item() <= 1e-4 * scale and (f32 - ref).abs().max().item() <= 1e-4 * scale
+    assert (x3 - f32).abs().max().item() <= 5e-5 * scale
+    assert not torch.equal(x3, f32)  # (two different kernels really ran)
