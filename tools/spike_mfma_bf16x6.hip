@@ -9,7 +9,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int MODE, int OCC>
+template <int MODE, int OCC, int MT = 2>
 __global__ __launch_bounds__(256, OCC) void k6(float* out, const uint4* __restrict__ w, const uint4* __restrict__ xg, int nchunks, int ntap, int adil) {
   extern __shared__ uint4 xs[];  // 2 buffers x [plane 3][group 2][kh 2][XW] 16-byte units (8 channels of one column)
   const int XW = 128 + (ntap - 1) * adil;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, OCC) void k6(float* out, const uint4* __restri
       }
       const int bb = MODE >= 1 ? (g & 1) : 0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           // smallest terms first: l*h, h*l, m*m, m*h, h*m, h*h
@@ -101,24 +101,24 @@ __global__ __launch_bounds__(256, OCC) void k6(float* out, const uint4* __restri
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-template <int MODE, int OCC>
+template <int MODE, int OCC, int MT = 2>
 void run(const char* name, float* out, uint4* w, uint4* xg, int ntap, int adil) {
   const int nchunks = 24, grid = 256 * OCC * 4;
   const int XW = 128 + (ntap - 1) * adil;
   const size_t smem = (size_t)2 * 12 * XW * 16;
-  hipFuncSetAttribute((const void*)k6<MODE, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipFuncSetAttribute((const void*)k6<MODE, OCC, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL((k6<MODE, OCC>), dim3(grid), dim3(256), smem, 0, out, w, xg, 2, ntap, adil);
+  hipLaunchKernelGGL((k6<MODE, OCC, MT>), dim3(grid), dim3(256), smem, 0, out, w, xg, 2, ntap, adil);
   hipEventRecord(e0, 0);
-  hipLaunchKernelGGL((k6<MODE, OCC>), dim3(grid), dim3(256), smem, 0, out, w, xg, nchunks, ntap, adil);
+  hipLaunchKernelGGL((k6<MODE, OCC, MT>), dim3(grid), dim3(256), smem, 0, out, w, xg, nchunks, ntap, adil);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   // per wave and (chunk, tap): 2 groups x 4 tiles x (32 x 32 x 16) MACs, fp32-equivalent
-  const double fl = (double)grid * 4 * nchunks * ntap * 2 * 4 * 2.0 * 32 * 32 * 16;
+  const double fl = (double)grid * 4 * nchunks * ntap * 2 * (2 * MT) * 2.0 * 32 * 32 * 16;
   printf("%-52s k=%2d d=%d smem %3zu KB %8.3f ms  %7.1f TFLOP/s fp32-equivalent (%6.0f bf16)\n", name, ntap, adil, smem >> 10, ms, fl / ms / 1e9, 6 * fl / ms / 1e9);
 }
 
@@ -136,6 +136,13 @@ int main() {
     run<2, 2>("+ A (3 planes) from L2, occ 2", out, w, xg, ntap, 1);
     run<3, 2>("+ 16-byte LDS-DMA of the next x tile + barrier, occ 2", out, w, xg, ntap, 1);
     run<3, 2>("   same, dilation 5", out, w, xg, ntap, 5);
+    run<0, 1>("2 x 2 tiles, operands in registers, ONE wave per SIMD", out, w, xg, ntap, 1);
+    run<1, 1>("   + B from LDS, one wave per SIMD", out, w, xg, ntap, 1);
+    run<0, 1, 1>("1 x 2 tiles, operands in registers, one wave per SIMD", out, w, xg, ntap, 1);
+    run<1, 1, 1>("   + B from LDS, one wave per SIMD", out, w, xg, ntap, 1);
+    run<0, 2, 1>("1 x 2 tiles per wave: operands in registers", out, w, xg, ntap, 1);
+    run<1, 2, 1>("1 x 2 tiles per wave: + B from LDS (6 reads per 12 MFMAs)", out, w, xg, ntap, 1);
+    run<1, 3, 1>("   same, 3 waves per SIMD", out, w, xg, ntap, 1);
   }
   return 0;
 }

@@ -13,33 +13,15 @@
 // lane^32, which holds the other half of the keys).  One workgroup = 4 waves = 128 queries; K/V tiles of 64 keys in LDS.
 //
 // Roofline: 4*T^2*d flops per head (fp32 MFMA peak 157.3 TFLOP/s); K/V re-read T/64 times from L2 (1.2 MB per head).
-#include "common.h"
+#include "attn_full.h"
 
 namespace ixtts {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int AF_D = 64;        // head dim
-constexpr int AF_KT = 64;       // keys per tile
-constexpr int AF_QW = 32;       // queries per wave
-constexpr int AF_WAVES = 4;
-constexpr int AF_KSPLIT = 4;   // key-range splits when the grid is too small (see attn_full_f32_kernel)
 // K tile pitch (floats): rows stay 16-byte aligned (ds_write_b128 / ds_read_b128) and 8 consecutive keys start 17
 // granules apart -> the 8 lanes a b128 read serves per cycle hit 8 different granules mod 8: conflict-free
 constexpr int AF_KP = AF_D + 4;
-
-struct AttnFullArgs {
-  const float* q;  // element (b, t, h, d) at q[b*sb + t*st + h*sh + d]
-  const float* k;
-  const float* v;
-  float* o;        // same strides as q (separate base)
-  long sb, st, sh;       // q/k/v strides in floats
-  long osb, ost, osh;    // output strides
-  int B, H, T;
-  float scale;
-  float* ws_o;   // KSPLIT > 1: un-normalised partial outputs [split][B][H][T][64]
-  float* ws_ml;  //             and their (running max in log2 units, sum) [split][B][H][T][2]
-};
 
 // The contraction index of S^T = K Q^T is free to permute: k-step kk = 4m + i of lane half lh uses d = 8m + 4 lh + i, so a
 // lane's four consecutive k-steps are one 16-byte LDS read of K (and one 16-byte global read of Q).
@@ -230,9 +212,13 @@ __global__ __launch_bounds__(256) void attn_full_merge_kernel(AttnFullArgs a) {
 
 }  // namespace ixtts
 
+static size_t attn_partials_bytes(int B, int H, int T) {
+  return (size_t)(ixtts::AF_KSPLIT > ixtts::AX_KSPLIT ? ixtts::AF_KSPLIT : ixtts::AX_KSPLIT) * B * H * T * (ixtts::AF_D + 2) * sizeof(float);
+}
+
 extern "C" size_t ixtts_attn_full_workspace_bytes(int B, int H, int T) {
   if (B <= 0 || H <= 0 || T <= 0) return 0;
-  return (size_t)ixtts::AF_KSPLIT * B * H * T * (ixtts::AF_D + 2) * sizeof(float);
+  return attn_partials_bytes(B, H, T) + ixtts::attn_full_x3_plane_bytes(B, H, T);
 }
 
 extern "C" int ixtts_attn_full_f32(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, int B, int H, int T,
@@ -252,11 +238,26 @@ extern "C" int ixtts_attn_full_f32(const float* q_dev, const float* k_dev, const
   hipStream_t st = (hipStream_t)stream;
   const int qblocks = ceil_div(T, AF_WAVES * AF_QW);
   // split the keys when the un-split grid cannot give every SIMD two waves and the caller brought the workspace
-  const bool split = workspace_dev && workspace_bytes >= ixtts_attn_full_workspace_bytes(B, H, T) && T > 4 * AF_KT &&
-                     (long)qblocks * B * H * AF_WAVES < 2 * 1024;
+  const bool have_ws = workspace_dev && workspace_bytes >= ixtts_attn_full_workspace_bytes(B, H, T);
+  const bool split = have_ws && T > 4 * AF_KT && (long)qblocks * B * H * AF_WAVES < 2 * 1024;
+  // default arithmetic: six bf16 MFMA partial products of exactly split operands (attn_full_x3.hip); IXTTS_ATTN_FULL=f32, or a
+  // caller without the workspace for the operand planes: the fp32-MFMA kernel below
+  static const bool x3 = [] { const char* e = getenv("IXTTS_ATTN_FULL"); return !(e && strcmp(e, "f32") == 0); }();
+  const bool use_x3 = x3 && have_ws;
   if (split) {
     a.ws_o = reinterpret_cast<float*>(workspace_dev);
-    a.ws_ml = a.ws_o + (size_t)AF_KSPLIT * B * H * T * AF_D;
+    a.ws_ml = a.ws_o + (size_t)(use_x3 ? AX_KSPLIT : AF_KSPLIT) * B * H * T * AF_D;
+  }
+  if (use_x3) {
+    IX_TRY(launch_attn_full_x3(a, reinterpret_cast<char*>(workspace_dev) + attn_partials_bytes(B, H, T), split, st));
+    if (split) {
+      const long rows = (long)B * H * T;
+      hipLaunchKernelGGL(attn_full_merge_kernel<AX_KSPLIT>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
+    }
+    IX_HIP(hipGetLastError());
+    return IXTTS_OK;
+  }
+  if (split) {
     hipLaunchKernelGGL(attn_full_f32_kernel<AF_KSPLIT>, dim3(qblocks, B * H, AF_KSPLIT), dim3(AF_WAVES * 64), 0, st, a);
     const long rows = (long)B * H * T;
     hipLaunchKernelGGL(attn_full_merge_kernel<AF_KSPLIT>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
