@@ -468,8 +468,12 @@ def main():
             torch.cuda.synchronize()
             us_a = e0.elapsed_time(e1) * 1e3 / 20
             fl = 4.0 * 2 * 8 * Ta * Ta * 64
-            stage_roof["s2mel_attention"] = {"bound": "mfma", "kernel": "attn_full_f32_kernel + merge (B=2, H=8, T=%d)" % Ta, "achieved": round(fl / us_a / 1e6, 1),
-                                             "peak": PEAK_F32, "unit": "TFLOP/s", "frac": round(fl / us_a / 1e6 / PEAK_F32, 3), "us_per_call": round(us_a, 1)}
+            x3a = os.environ.get("IXTTS_ATTN_FULL", "x3") != "f32"
+            tf_a, peak_a = fl / us_a / 1e6, (PEAK_BF16 / 6 if x3a else PEAK_F32)
+            stage_roof["s2mel_attention"] = {"bound": "mfma", "kernel": ("attn_kv_planes + attn_full_x3_kernel + merge" if x3a else "attn_full_f32_kernel + merge") + " (B=2, H=8, T=%d)" % Ta,
+                                             "achieved": round(tf_a, 1), "peak": round(peak_a, 1), "unit": "TFLOP/s", "frac": round(tf_a / peak_a, 3), "us_per_call": round(us_a, 1),
+                                             "arithmetic": "fp32-equivalent flops; six bf16 MFMA partial products per fp32 product, fp32 accumulate" if x3a else "fp32 MFMA",
+                                             "fp32_mfma_peak": PEAK_F32, "frac_of_fp32_mfma_peak": round(tf_a / PEAK_F32, 3)}
 
     # ---- extra figures of the default line (driver-visible): config 5, the served 3-beam default, fp32 parity mode, step per B
     extra = None
@@ -617,7 +621,7 @@ def main():
                 "codes_per_segment": n_codes if not mixed else "11 per token", "mel_frames_per_segment": frames if not mixed else "floor(1.72 codes)",
                 "audio_seconds_per_step": round(total_audio / args.steps, 3), "parallelism": f"request-per-GPU x{world}, RCCL weight broadcast at load",
                 "gpt_precision": f"{args.dtype} weights+KV, fp32 accumulate", "bigvgan_precision": "fp32 tensors; conv products as six bf16 MFMA partial products of exactly split operands, fp32 accumulate" if os.environ.get("IXTTS_BV_CONV", "x3") != "f32" else "fp32 (fp32 MFMA)",
-                "s2mel": "torch fp32 glue + HIP attention / row kernels in the timed region" if use_s2mel else "excluded",
+                "s2mel": "torch fp32 glue (library fp32 GEMMs) + HIP attention (split-product bf16 MFMA, fp32-accurate) / row kernels in the timed region" if use_s2mel else "excluded",
                 "conditioning": "torch fp32 glue in the timed region (inside gpt_gen)" if use_cond else "excluded",
             },
             "stage_ms_per_step": {k: round(v / args.steps, 2) for k, v in stage_ms.items()},

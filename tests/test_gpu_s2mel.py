@@ -56,6 +56,27 @@ def test_attn_full_f32_vs_torch_sdpa(B, H, T):
     assert (out2 - ref2).abs().max().item() <= 2e-5 * max(1.0, ref2.abs().max().item())
 
 
+def test_attn_full_arithmetic_modes_agree(monkeypatch):
+    """attn_full_x3.hip (operands as three bf16 pieces, six partial products, fp32 accumulate; the default) against attn_full.hip
+    (fp32 MFMA, IXTTS_ATTN_FULL=f32) on the production shape: both within 2e-5 of fp64 attention, and of each other."""
+    from voice_tts_amd.s2mel import attn_full
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(77)
+    B, H, T = 2, 8, 2322
+    qkv = (torch.randn(B, T, 3, H, 64, generator=g) * 1.5).to(dev)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    ref = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2).double(), k.transpose(1, 2).double(), v.transpose(1, 2).double()).transpose(1, 2)
+    x3 = attn_full(q, k, v)
+    monkeypatch.setenv("IXTTS_ATTN_FULL", "f32")
+    f32 = attn_full(q, k, v)
+    scale = max(1.0, ref.abs().max().item())
+    e_x3, e_f32 = (x3.double() - ref).abs().max().item(), (f32.double() - ref).abs().max().item()
+    assert e_x3 <= 2e-5 * scale and e_f32 <= 2e-5 * scale, (e_x3, e_f32)
+    assert e_x3 <= 3.0 * e_f32 + 1e-7, (e_x3, e_f32)  # the same quality of result, not merely inside the bound
+    assert not torch.equal(x3, f32)  # (two different kernels really ran)
+
+
 def test_dit_row_ops_match_torch(dev):
     """csrc/dit_ops.hip against the torch formulas they replace (the CPU branch of the same functions), fp32, <= 2e-6 * max."""
     from voice_tts_amd import s2mel as S

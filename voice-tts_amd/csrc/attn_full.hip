@@ -242,7 +242,8 @@ extern "C" int ixtts_attn_full_f32(const float* q_dev, const float* k_dev, const
   const bool split = have_ws && T > 4 * AF_KT && (long)qblocks * B * H * AF_WAVES < 2 * 1024;
   // default arithmetic: six bf16 MFMA partial products of exactly split operands (attn_full_x3.hip); IXTTS_ATTN_FULL=f32, or a
   // caller without the workspace for the operand planes: the fp32-MFMA kernel below
-  static const bool x3 = [] { const char* e = getenv("IXTTS_ATTN_FULL"); return !(e && strcmp(e, "f32") == 0); }();
+  const char* mode = getenv("IXTTS_ATTN_FULL");  // (read per call: the parity tests run both builds in one process)
+  const bool x3 = !(mode && strcmp(mode, "f32") == 0);
   const bool use_x3 = x3 && have_ws;
   if (split) {
     a.ws_o = reinterpret_cast<float*>(workspace_dev);
