@@ -56,8 +56,11 @@ int ixtts_aa_snake_f32(const float* x_dev, float* y_dev, const float* up12_dev, 
  *   indextts/s2mel/modules/gpt_fast/model.py:303 (called from diffusion_transformer.py:238)
  * q, k, v, out: fp32, element (b, t, h, d) at base[b*stride_b + t*stride_t + h*stride_h + d] (d contiguous,
  * head_dim 64, strides in floats and multiples of 4); out = softmax(scale * q k^T) v per (b, h).
- * workspace_dev (optional, ixtts_attn_full_workspace_bytes(B,H,T) bytes of scratch owned by the caller): lets the kernel
- * split the key range over four workgroups per query block when the un-split grid cannot fill the GPU, plus a merge pass.
+ * workspace_dev (optional, ixtts_attn_full_workspace_bytes(B,H,T) bytes of scratch owned by the caller): holds the K / V operand
+ * planes of the default kernel (csrc/attn_full_x3.hip: every fp32 product as six bf16 MFMA partial products of exactly split
+ * operands, fp32 accumulate -- fp32-quality results, tests/test_gpu_s2mel.py) and the partials of the key-range split it uses when
+ * the un-split grid cannot fill the GPU (+ a merge pass).  Without it, or with IXTTS_ATTN_FULL=f32 in the environment, the
+ * fp32-MFMA kernel of csrc/attn_full.hip runs.
  */
 size_t ixtts_attn_full_workspace_bytes(int B, int H, int T);
 int ixtts_attn_full_f32(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, int B, int H, int T,
