@@ -50,8 +50,9 @@ def traffic(fetch_dir, write_dir, dst, command):
         out["bigvgan_forward"] = {"forwards": n_fwd, "hbm_bytes_per_forward": (2.0 * fi + wi) * 1024.0 / n_fwd,
                                   "fetch_bytes_per_forward": 2.0 * fi * 1024.0 / n_fwd, "fetch_bytes_per_forward_uncorrected": fi * 1024.0 / n_fwd,
                                   "write_bytes_per_forward": wi * 1024.0 / n_fwd,
-                                  "caveat": "the x2 FETCH_SIZE correction is calibrated for 16 B/lane streams; the conv x tiles (LDS-DMA, 4 B/lane) and the "
-                                            "Snake passes (4 B/lane) are outside that calibration: the true fetch volume lies between the two figures"}
+                                  "caveat": "the x2 FETCH_SIZE correction is calibrated for 16 B/lane streams (the split-product convs' weight and x-plane "
+                                            "loads are such streams); the Snake passes read 4 B/lane (and the fp32-MFMA build's x tiles are 4 B/lane LDS-DMA): "
+                                            "for those the true fetch volume lies between the two figures"}
     json.dump(out, open(dst, "w"), indent=1)
     for k, v in res.items():
         print(f"{v['hbm_bytes_per_launch'] / 1e6:10.3f} MB  x{v['launches']:5d}  {short(k)[:100]}")
