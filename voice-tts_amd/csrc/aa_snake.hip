@@ -168,20 +168,6 @@ constexpr int AP_TILE = 256;
 constexpr int AP_NX = AP_TILE + 2 * AA_XH;
 constexpr int AP_NS = 2 * AP_TILE + 16;
 
-__device__ __forceinline__ void split8_planes(const float (&v)[8], uint4& ph, uint4& pm, uint4& pl) {
-  unsigned int h[8], m[8], l[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    h[e] = __float_as_uint(v[e]) + 0x8000u;  // round to nearest (ties away): truncated pieces would all err the same way
-    const float r = v[e] - __uint_as_float(h[e] & 0xffff0000u);
-    m[e] = __float_as_uint(r) + 0x8000u;
-    l[e] = __float_as_uint(r - __uint_as_float(m[e] & 0xffff0000u));  // exact: at most 8 significant bits are left
-  }
-  auto pk = [](unsigned int hi, unsigned int lo) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); };
-  ph = make_uint4(pk(h[1], h[0]), pk(h[3], h[2]), pk(h[5], h[4]), pk(h[7], h[6]));
-  pm = make_uint4(pk(m[1], m[0]), pk(m[3], m[2]), pk(m[5], m[4]), pk(m[7], m[6]));
-  pl = make_uint4(pk(l[1], l[0]), pk(l[3], l[2]), pk(l[5], l[4]), pk(l[7], l[6]));
-}
 
 template <bool FAST_SIN>
 __global__ __launch_bounds__(512) void aa_snake_planes_kernel(const float* __restrict__ x, uint4* __restrict__ xp, const float* __restrict__ up12,
@@ -282,7 +268,7 @@ __global__ __launch_bounds__(512) void aa_snake_planes_kernel(const float* __res
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = ys[e][threadIdx.x];
     uint4 ph, pm, pl;
-    split8_planes(v, ph, pm, pl);
+    split8_bf16x3(v, ph, pm, pl);
     uint4* dst = xp + ((size_t)b * 3 * C8 + o) * T + t0 + threadIdx.x;
     dst[0] = ph;
     dst[(size_t)C8 * T] = pm;

@@ -31,20 +31,6 @@ size_t attn_full_x3_plane_bytes(int B, int H, int T) {
   return (size_t)B * H * tiles * 2 * AX_TILE_UNITS * 16;
 }
 
-__device__ __forceinline__ void ax_split8(const float (&v)[8], uint4& ph, uint4& pm, uint4& pl) {
-  unsigned int h[8], m[8], l[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    h[e] = __float_as_uint(v[e]) + 0x8000u;  // round to nearest (ties away): truncated pieces would all err the same way
-    const float r = v[e] - __uint_as_float(h[e] & 0xffff0000u);
-    m[e] = __float_as_uint(r) + 0x8000u;
-    l[e] = __float_as_uint(r - __uint_as_float(m[e] & 0xffff0000u));  // exact: at most 8 significant bits are left
-  }
-  auto pk = [](unsigned int hi, unsigned int lo) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); };
-  ph = make_uint4(pk(h[1], h[0]), pk(h[3], h[2]), pk(h[5], h[4]), pk(h[7], h[6]));
-  pm = make_uint4(pk(m[1], m[0]), pk(m[3], m[2]), pk(m[5], m[4]), pk(m[7], m[6]));
-  pl = make_uint4(pk(l[1], l[0]), pk(l[3], l[2]), pk(l[5], l[4]), pk(l[7], l[6]));
-}
 
 // ---- split pass: one workgroup per (64-key tile, batch*head).
 //   K block  [plane][oct 8][key 64]: unit = d 8*oct .. 8*oct+7 of one key (the A operand of S^T for lane (key, kh = oct & 1))
@@ -70,7 +56,7 @@ __global__ __launch_bounds__(256) void attn_kv_planes_kernel(AttnFullArgs a, uin
     v[0] = live ? x0.x : 0.f; v[1] = live ? x0.y : 0.f; v[2] = live ? x0.z : 0.f; v[3] = live ? x0.w : 0.f;
     v[4] = live ? x1.x : 0.f; v[5] = live ? x1.y : 0.f; v[6] = live ? x1.z : 0.f; v[7] = live ? x1.w : 0.f;
     uint4 ph, pm, pl;
-    ax_split8(v, ph, pm, pl);
+    split8_bf16x3(v, ph, pm, pl);
     kdst[(0 * 8 + oct) * 64 + key] = ph;
     kdst[(1 * 8 + oct) * 64 + key] = pm;
     kdst[(2 * 8 + oct) * 64 + key] = pl;
@@ -87,7 +73,7 @@ __global__ __launch_bounds__(256) void attn_kv_planes_kernel(AttnFullArgs a, uin
       v[e] = t < a.T ? x : 0.f;
     }
     uint4 ph, pm, pl;
-    ax_split8(v, ph, pm, pl);
+    split8_bf16x3(v, ph, pm, pl);
     vdst[(0 * 8 + un) * 64 + d] = ph;
     vdst[(1 * 8 + un) * 64 + d] = pm;
     vdst[(2 * 8 + un) * 64 + d] = pl;
@@ -115,7 +101,7 @@ __global__ __launch_bounds__(AX_WAVES * 64, 2) void attn_full_x3_kernel(AttnFull
     for (int s = 0; s < 4; ++s) {
       const float4 x0 = *reinterpret_cast<const float4*>(qrow + 16 * s), x1 = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
       const float v[8] = {x0.x * qs, x0.y * qs, x0.z * qs, x0.w * qs, x1.x * qs, x1.y * qs, x1.z * qs, x1.w * qs};
-      ax_split8(v, qp[s][0], qp[s][1], qp[s][2]);
+      split8_bf16x3(v, qp[s][0], qp[s][1], qp[s][2]);
     }
   }
   ax_f32x16 ot[2];  // O^T tiles: d 0..31, 32..63 (rows d in registers, column = this lane's query)
@@ -253,7 +239,7 @@ __global__ __launch_bounds__(AX_WAVES * 64, 2) void attn_full_x3_kernel(AttnFull
         float pv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) pv[e] = st[j][8 * u + e];
-        ax_split8(pv, pp[0], pp[1], pp[2]);
+        split8_bf16x3(pv, pp[0], pp[1], pp[2]);
       }
       __builtin_amdgcn_sched_barrier(0);
       mfma6x2(ot[0], ot[1], va[s & 1][0], va[s & 1][1], pp);

@@ -123,4 +123,23 @@ __device__ __forceinline__ int wave_min_i32_dpp(int v) {
   return __builtin_amdgcn_readlane(s, 63);
 }
 
+// ---- fp32 -> three bf16 pieces (the split-product kernels: conv1d_x3.hip, attn_full_x3.hip, aa_snake.hip)
+// v = h + m + l EXACTLY: each piece is the remainder before it rounded to 8 significant bits (to nearest, ties away: truncated
+// pieces would all err the same way in the products that are dropped); at most 8 significant bits are left for l.  Eight values
+// become three 16-byte units of eight bf16: word w of a unit = values (2w, 2w+1), value 2w in the low 16 bits.
+__device__ __forceinline__ void split8_bf16x3(const float (&v)[8], uint4& ph, uint4& pm, uint4& pl) {
+  unsigned int h[8], m[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = __float_as_uint(v[e]) + 0x8000u;
+    const float r = v[e] - __uint_as_float(h[e] & 0xffff0000u);
+    m[e] = __float_as_uint(r) + 0x8000u;
+    l[e] = __float_as_uint(r - __uint_as_float(m[e] & 0xffff0000u));
+  }
+  auto pk = [](unsigned int hi, unsigned int lo) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); };  // the high halves of both
+  ph = make_uint4(pk(h[1], h[0]), pk(h[3], h[2]), pk(h[5], h[4]), pk(h[7], h[6]));
+  pm = make_uint4(pk(m[1], m[0]), pk(m[3], m[2]), pk(m[5], m[4]), pk(m[7], m[6]));
+  pl = make_uint4(pk(l[1], l[0]), pk(l[3], l[2]), pk(l[5], l[4]), pk(l[7], l[6]));
+}
+
 }  // namespace ixtts

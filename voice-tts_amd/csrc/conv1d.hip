@@ -24,7 +24,7 @@
 
 namespace ixtts {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef conv_f32x16 f32x16;
 
 constexpr int CG = 8;   // input channels per weight group (one float4 per lane = 4 MFMA k-steps)
 // CKG groups per K-chunk (template parameter): the x tile in LDS covers 8 CKG input channels -- 32, or 24 for the 24- / 48-channel
@@ -183,49 +183,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : 2)) void conv1d_mfma_kernel(Con
   for (int g = 0; g < nchunks; ++g) chunk_step(g, Xs + (g & 1) * bufsz, Xs + ((g + 1) & 1) * bufsz);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus copy of the last iteration, before the workgroup's LDS is released
 
-  // ---- epilogue: bias, residual, 3-way accumulate, /3.  Every operand load is unconditional and issued before the first
-  // store of its 32x32 block (absent operands and out-of-range elements read the zero page / a clamped element): loads
-  // under the bounds branch were waited for one by one, 64+ dependent round trips per lane.
-  const size_t ob = (size_t)b * p.Cout * p.Tout;
-  const int ophase = p.oo + (p.nphase > 1 ? phase : 0);
-  float bv[MT][16];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = min(m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.Cout - 1);
-      bv[i][r] = *(p.bias ? p.bias + m : p.zeros);
-    }
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int q = q0 + wn * (32 * NT) + j * 32 + l31;
-      const int t = q * p.os + ophase;
-      const bool tv = (q < p.Nq) && (t >= 0) && (t < p.Tout);
-      const int tc = min(max(t, 0), p.Tout - 1);
-      float rv[16], av[16], av2[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = min(m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.Cout - 1);
-        const size_t o = ob + (size_t)m * p.Tout + tc;
-        rv[r] = *(p.res ? p.res + o : p.zeros);
-        av[r] = *(p.accum ? p.accum + o : p.zeros);
-        av2[r] = *(p.accum2 ? p.accum2 + o : p.zeros);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float v = acc[i][j][r];
-        if (p.bias) v += bv[i][r];
-        if (p.res) v += rv[r];
-        if (p.accum2) v = (av[r] + av2[r]) + v;  // xs = r0; xs += r1; xs += r2 (bigvgan.py:369-375): same order
-        else if (p.accum) v = av[r] + v;
-        if (p.div3) v = v / 3.0f;
-        if (tv && m < p.Cout) p.y[ob + (size_t)m * p.Tout + t] = v;
-      }
-    }
-  }
+  conv_epilogue<MT, NT>(p, acc, m0 + wm * (32 * MT), q0 + wn * (32 * NT), b, phase, l31, lh);
 }
 
 template <int MT, int NT, int WM, int WN, int CKG = 4, bool RAGGED = true>

@@ -20,7 +20,7 @@
 
 namespace ixtts {
 
-typedef float cx_f32x16 __attribute__((ext_vector_type(16)));
+typedef conv_f32x16 cx_f32x16;
 typedef __bf16 cx_bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int MT, int NT, int WM, int WN>
@@ -169,47 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_x3_kernel(ConvParams p) {
   for (int g = 0; g < nchunks; ++g) chunk_step(g, Xq + (g & 1) * bufsz, Xq + ((g + 1) & 1) * bufsz);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus copy of the last iteration, before the workgroup's LDS is released
 
-  // ---- epilogue (as conv1d.hip): bias, residual, 3-way accumulate, /3; operand loads unconditional, before the stores
-  const size_t ob = (size_t)b * p.Cout * p.Tout;
-  const int ophase = p.oo + (p.nphase > 1 ? phase : 0);
-  float bv[MT][16];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = min(m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.Cout - 1);
-      bv[i][r] = *(p.bias ? p.bias + m : p.zeros);
-    }
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int q = q0 + wn * (32 * NT) + j * 32 + l31;
-      const int t = q * p.os + ophase;
-      const bool tv = (q < p.Nq) && (t >= 0) && (t < p.Tout);
-      const int tc = min(max(t, 0), p.Tout - 1);
-      float rv[16], av[16], av2[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = min(m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.Cout - 1);
-        const size_t o = ob + (size_t)m * p.Tout + tc;
-        rv[r] = *(p.res ? p.res + o : p.zeros);
-        av[r] = *(p.accum ? p.accum + o : p.zeros);
-        av2[r] = *(p.accum2 ? p.accum2 + o : p.zeros);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float v = acc[i][j][r];
-        if (p.bias) v += bv[i][r];
-        if (p.res) v += rv[r];
-        if (p.accum2) v = (av[r] + av2[r]) + v;  // xs = r0; xs += r1; xs += r2 (bigvgan.py:369-375): same order
-        else if (p.accum) v = av[r] + v;
-        if (p.div3) v = v / 3.0f;
-        if (tv && m < p.Cout) p.y[ob + (size_t)m * p.Tout + t] = v;
-      }
-    }
-  }
+  conv_epilogue<MT, NT>(p, acc, m0 + wm * (32 * MT), q0 + wn * (32 * NT), b, phase, l31, lh);
 }
 
 template <int MT, int NT, int WM, int WN>
@@ -274,21 +234,6 @@ int launch_conv1d_x3(const ConvParams& p, hipStream_t st) {
 // fp32 [B][C][T] -> x planes [B][3][C8][T][8] bf16 (the inputs that do not come from a Snake pass: the mel, the stage outputs
 // the transposed convs read).  One (octet, time step) per thread: eight strided 4-byte reads (coalesced across the wave),
 // three 16-byte writes.
-__device__ __forceinline__ void split8_rn(const float (&v)[8], uint4& ph, uint4& pm, uint4& pl) {
-  unsigned int h[8], m[8], l[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    h[e] = __float_as_uint(v[e]) + 0x8000u;  // round to nearest (ties away): truncated pieces would all err the same way
-    const float r = v[e] - __uint_as_float(h[e] & 0xffff0000u);
-    m[e] = __float_as_uint(r) + 0x8000u;
-    l[e] = __float_as_uint(r - __uint_as_float(m[e] & 0xffff0000u));  // exact: at most 8 significant bits are left
-  }
-  // word w of a unit = channels (2w, 2w+1): the high halves of both, channel 2w in the low 16 bits
-  auto pk = [](unsigned int hi, unsigned int lo) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); };
-  ph = make_uint4(pk(h[1], h[0]), pk(h[3], h[2]), pk(h[5], h[4]), pk(h[7], h[6]));
-  pm = make_uint4(pk(m[1], m[0]), pk(m[3], m[2]), pk(m[5], m[4]), pk(m[7], m[6]));
-  pl = make_uint4(pk(l[1], l[0]), pk(l[3], l[2]), pk(l[5], l[4]), pk(l[7], l[6]));
-}
 
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint4* __restrict__ xp, int C, int T) {
   const int C8 = (C + 7) >> 3;
@@ -299,7 +244,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = (o * 8 + e < C) ? xb[(size_t)(o * 8 + e) * T + t] : 0.f;
   uint4 ph, pm, pl;
-  split8_rn(v, ph, pm, pl);
+  split8_bf16x3(v, ph, pm, pl);
   uint4* dst = xp + ((size_t)b * 3 * C8 + o) * T + t;
   dst[0] = ph;
   dst[(size_t)C8 * T] = pm;
