@@ -10,7 +10,7 @@ constexpr int AF_KT = 64;       // keys per tile
 constexpr int AF_QW = 32;       // queries per wave
 constexpr int AF_WAVES = 4;
 constexpr int AF_KSPLIT = 4;    // key-range splits when the grid is too small (see attn_full_f32_kernel)
-constexpr int AX_KSPLIT = 5;    // the same for attn_full_x3_kernel: 19 x 16 x 5 workgroups of 8 tiles = 3 rounds of 512 slots (4 splits: 3 rounds of 10)
+constexpr int AX_KSPLIT = 5;    // the same for attn_full_x3_kernel: 19 x 16 x 5 workgroups of <= 8 tiles = 2 rounds of 768 slots (4 splits: 2 rounds of 10)
 
 struct AttnFullArgs {
   const float* q;  // element (b, t, h, d) at q[b*sb + t*st + h*sh + d]

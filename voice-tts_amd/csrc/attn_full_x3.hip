@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void attn_kv_planes_kernel(AttnFullArgs a, uin
 }
 
 template <int KSPLIT>
-__global__ __launch_bounds__(AX_WAVES * 64, 2) void attn_full_x3_kernel(AttnFullArgs a, const uint4* __restrict__ planes) {
+__global__ __launch_bounds__(AX_WAVES * 64, 3) void attn_full_x3_kernel(AttnFullArgs a, const uint4* __restrict__ planes) {
   __shared__ uint4 Ks[AX_TILE_UNITS];  // [plane][oct][key]
   __shared__ uint4 Vs[AX_TILE_UNITS];  // [plane][unit][d]
   const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
@@ -142,7 +142,9 @@ __global__ __launch_bounds__(AX_WAVES * 64, 2) void attn_full_x3_kernel(AttnFull
     c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, bh_, c1, 0, 0, 0);
   };
   // ---- the tile loop: two barriers per 64-key tile; V(t) is copied under the S^T MFMAs and the softmax of tile t, K(t+1) under
-  // the PV MFMAs.  Tried and measured on (B=2, H=8, T=2322), whole call: this form with 4 key splits 172 us; K double-buffered a
+  // the PV MFMAs.  Three workgroups per CU: the A fragments of a step are read right before its MFMAs (no second register set
+  // for a step-ahead prefetch: 165 VGPRs instead of 205) and the third resident wave covers their LDS latency: 157 us against
+  // 172 with two.  Tried and measured on (B=2, H=8, T=2322), whole call, at two per CU: this form 172 us; K double-buffered a
   // tile ahead 172; tile copies through registers + ds_write 236; 8-wave workgroups (256 queries per staged tile) 194; 8 waves as
   // two anti-phase halves (four barriers per tile, one half in an MFMA segment while the other does its softmax) 196 -- a 48-MFMA
   // segment is short against a barrier (0.15-0.3 us each) and the clock sits near 1.9 GHz under this load; work ids grouped per
@@ -155,28 +157,21 @@ __global__ __launch_bounds__(AX_WAVES * 64, 2) void attn_full_x3_kernel(AttnFull
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     issue_tile(pb + ((size_t)tile * 2 + 1) * AX_TILE_UNITS, Vs);
-    // ---- S^T = K Q^T for the two 32-key halves: A = K units (plane, oct 2s + lh, key), one step ahead of the MFMAs
+    // ---- S^T = K Q^T for the two 32-key halves: A = K units (plane, oct 2s + lh, key)
     ax_f32x16 st[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[j][r] = 0.f;
     const uint4* kp = Ks + lh * 64 + l31;
-    uint4 ka[2][2][3];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) ka[0][j][pl] = kp[(pl * 8) * 64 + 32 * j];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (s + 1 < 4) {
+      uint4 ka[2][3];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) ka[(s + 1) & 1][j][pl] = kp[(pl * 8 + 2 * (s + 1)) * 64 + 32 * j];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mfma6x2(st[0], st[1], ka[s & 1][0], ka[s & 1][1], qp[s]);
+        for (int pl = 0; pl < 3; ++pl) ka[j][pl] = kp[(pl * 8 + 2 * s) * 64 + 32 * j];
+      mfma6x2(st[0], st[1], ka[0], ka[1], qp[s]);
     }
     // ---- online softmax for this lane's query; keys beyond T are masked (only the last tile has any)
     if (t0 + AF_KT > a.T) {
@@ -218,22 +213,16 @@ __global__ __launch_bounds__(AX_WAVES * 64, 2) void attn_full_x3_kernel(AttnFull
     __builtin_amdgcn_s_barrier();
     if (tile + 1 < tile_hi) issue_tile(pb + (size_t)(tile + 1) * 2 * AX_TILE_UNITS, Ks);
     // ---- O^T += V^T P^T: step (j, u) contracts the eight keys of registers 8u .. 8u+7 of half j (per lane half);
-    //      A = V units (plane, unit 4j + 2u + lh, d), read one step ahead; the weights are split right before their step
+    //      A = V units (plane, unit 4j + 2u + lh, d); the weights are split right before their step
     const uint4* vp = Vs + lh * 64 + l31;
-    uint4 va[2][2][3];
-#pragma unroll
-    for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) va[0][dh][pl] = vp[(pl * 8) * 64 + 32 * dh];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int j = s >> 1, u = s & 1;
-      if (s + 1 < 4) {
+      uint4 va[2][3];
 #pragma unroll
-        for (int dh = 0; dh < 2; ++dh)
+      for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) va[(s + 1) & 1][dh][pl] = vp[(pl * 8 + 2 * (s + 1)) * 64 + 32 * dh];
-      }
+        for (int pl = 0; pl < 3; ++pl) va[dh][pl] = vp[(pl * 8 + 2 * s) * 64 + 32 * dh];
       uint4 pp[3];
       {
         float pv[8];
@@ -241,8 +230,7 @@ __global__ __launch_bounds__(AX_WAVES * 64, 2) void attn_full_x3_kernel(AttnFull
         for (int e = 0; e < 8; ++e) pv[e] = st[j][8 * u + e];
         split8_bf16x3(pv, pp[0], pp[1], pp[2]);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      mfma6x2(ot[0], ot[1], va[s & 1][0], va[s & 1][1], pp);
+      mfma6x2(ot[0], ot[1], va[0], va[1], pp);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
