@@ -2,7 +2,8 @@
 // fp32 accumulate) in the conv kernel's loop shape.  Per 16-channel group and wave (2 x 2 tiles of 32 x 32): A = 3 planes x 2 row
 // tiles x 16 B from L2, B = 3 planes x 2 column tiles x ds_read_b128 from a channel-octet-interleaved LDS tile, 24 MFMAs
 // (v_mfma_f32_32x32x16_bf16).  Reports fp32-EQUIVALENT TFLOP/s (2 * M * N * K, not the 6x bf16 work).
-//   mode 0: MFMAs only; 1: + B from LDS; 2: + A from L2; 3: + per-chunk 16-byte LDS-DMA of the next x tile + barrier
+//   mode 0: MFMAs only; 1: + B from LDS; 2: + A from L2; 3: + per-chunk 16-byte LDS-DMA of the next x tile + barrier;
+//   4: as 3 but A arrives as fp32 (32 B per fragment instead of 48) and is split into its three planes in registers
 // hipcc --offload-arch=gfx950 -O3 tools/spike_mfma_bf16x6.hip -o /tmp/spike6 && /tmp/spike6
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -23,10 +24,37 @@ __global__ __launch_bounds__(256, OCC) void k6(float* out, const uint4* __restri
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   uint4 a_cur[2][3][2], a_nxt[2][3][2];  // [group][plane][row tile]
   const uint4* wq = w + lane;
+  auto split8 = [](const uint4& x0, const uint4& x1, uint4& ph, uint4& pm, uint4& pl) {
+    const unsigned int v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    unsigned int h[8], m[8], l[8];
+    for (int e = 0; e < 8; ++e) {
+      h[e] = v[e] + 0x8000u;
+      const float r = __uint_as_float(v[e]) - __uint_as_float(h[e] & 0xffff0000u);
+      m[e] = __float_as_uint(r) + 0x8000u;
+      l[e] = __float_as_uint(r - __uint_as_float(m[e] & 0xffff0000u));
+    }
+    auto pk = [](unsigned int hi, unsigned int lo) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); };
+    ph = make_uint4(pk(h[1], h[0]), pk(h[3], h[2]), pk(h[5], h[4]), pk(h[7], h[6]));
+    pm = make_uint4(pk(m[1], m[0]), pk(m[3], m[2]), pk(m[5], m[4]), pk(m[7], m[6]));
+    pl = make_uint4(pk(l[1], l[0]), pk(l[3], l[2]), pk(l[5], l[4]), pk(l[7], l[6]));
+  };
   auto load_a = [&](uint4 (&a)[2][3][2], int idx) {
     for (int g = 0; g < 2; ++g)
-      for (int p = 0; p < 3; ++p)
-        for (int i = 0; i < 2; ++i) a[g][p][i] = wq[((idx & 31) * 12 + (g * 3 + p) * 2 + i) * 64];
+      for (int i = 0; i < 2; ++i) {
+        if (MODE == 4) {  // planes 0, 1 hold the raw fp32 halves until split_a() turns them into the three planes
+          a[g][0][i] = wq[((idx & 31) * 12 + (g * 3 + 0) * 2 + i) * 64];
+          a[g][1][i] = wq[((idx & 31) * 12 + (g * 3 + 1) * 2 + i) * 64];
+        } else {
+          for (int p = 0; p < 3; ++p) a[g][p][i] = wq[((idx & 31) * 12 + (g * 3 + p) * 2 + i) * 64];
+        }
+      }
+  };
+  auto split_a = [&](uint4 (&a)[2][3][2]) {
+    for (int g = 0; g < 2; ++g)
+      for (int i = 0; i < 2; ++i) {
+        const uint4 x0 = a[g][0][i], x1 = a[g][1][i];
+        split8(x0, x1, a[g][0][i], a[g][1][i], a[g][2][i]);
+      }
   };
   auto load_b = [&](uint4 (&bq)[3][2], const uint4* xrow, int g) {
     for (int p = 0; p < 3; ++p)
@@ -46,6 +74,7 @@ __global__ __launch_bounds__(256, OCC) void k6(float* out, const uint4* __restri
   uint4 bcarry[3][2];
   auto run_tap = [&](const uint4* Xc, int gch, int tap) {
     if (MODE >= 2) load_a(a_nxt, gch * ntap + tap + 1);
+    if (MODE == 4) split_a(a_cur);
     const uint4* xrow = Xc + lh * XW + wn * 64 + l31 + tap * adil;
     const uint4* xrow_n = Xc + lh * XW + wn * 64 + l31 + (tap + 1 < ntap ? tap + 1 : tap) * adil;
     uint4 bq[2][3][2];
@@ -81,15 +110,15 @@ __global__ __launch_bounds__(256, OCC) void k6(float* out, const uint4* __restri
         for (int p = 0; p < 3; ++p)
           for (int i = 0; i < 2; ++i) a_cur[g][p][i] = a_nxt[g][p][i];
   };
-  if (MODE == 3) issue_dma(xs);
+  if (MODE >= 3) issue_dma(xs);
   load_a(a_cur, 0);
   auto chunk_step = [&](int g, const uint4* __restrict__ cur, uint4* __restrict__ nxt) {
-    if (MODE == 3) {
+    if (MODE >= 3) {
       asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
     run_tap(cur, g, 0);
-    if (MODE == 3) issue_dma(nxt);
+    if (MODE >= 3) issue_dma(nxt);
     for (int tap = 1; tap < ntap; ++tap) run_tap(cur, g, tap);
   };
   for (int g = 0; g < nchunks; ++g) chunk_step(g, xs + (g & 1) * bufsz, xs + ((g + 1) & 1) * bufsz);
@@ -136,6 +165,7 @@ int main() {
     run<2, 2>("+ A (3 planes) from L2, occ 2", out, w, xg, ntap, 1);
     run<3, 2>("+ 16-byte LDS-DMA of the next x tile + barrier, occ 2", out, w, xg, ntap, 1);
     run<3, 2>("   same, dilation 5", out, w, xg, ntap, 5);
+    run<4, 2>("   A as fp32 from L2 (32 B per fragment), split in registers", out, w, xg, ntap, 1);
     run<0, 1>("2 x 2 tiles, operands in registers, ONE wave per SIMD", out, w, xg, ntap, 1);
     run<1, 1>("   + B from LDS, one wave per SIMD", out, w, xg, ntap, 1);
     run<0, 1, 1>("1 x 2 tiles, operands in registers, one wave per SIMD", out, w, xg, ntap, 1);
