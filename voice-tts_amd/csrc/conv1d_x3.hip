@@ -225,9 +225,11 @@ int launch_conv1d_x3(const ConvParams& p, hipStream_t st) {
   if (p.Cout_pad == 64) return launch_x3_cfg<1, 2, 2, 2>(p, st);  // 64 x 128
   // (few taps per x tile -- the polyphase transposed convs have 2 to 4 -- and the tile copy weighs as much as the weights: the
   // 128-row tile halves both per flop: 252 against 369 us for the 768 -> 384 up-sampling conv)
-  const double s128 = x3_tile_score(p, 128, 128, 2, 1.00), s64 = x3_tile_score(p, 64, 128, 3, p.ntap >= 3 ? 0.93 : 0.65);
-  if (s128 >= s64) return launch_x3_cfg<1, 4, 4, 1>(p, st);        // 128 x 128
-  return launch_x3_cfg<1, 2, 2, 2>(p, st);                          // 64 x 128
+  const double s128 = x3_tile_score(p, 128, 128, 2, 1.00), s96 = x3_tile_score(p, 128, 96, 2, 0.96),
+               s64 = x3_tile_score(p, 64, 128, 3, p.ntap >= 3 ? 0.93 : 0.65);
+  if (s128 >= s64 && s128 >= s96) return launch_x3_cfg<1, 4, 4, 1>(p, st);  // 128 x 128
+  if (s96 >= s64) return launch_x3_cfg<1, 3, 4, 1>(p, st);                   // 128 x 96: e.g. 6 x 79 tiles on 512 slots where 6 x 60 leave 30 % idle
+  return launch_x3_cfg<1, 2, 2, 2>(p, st);                                   // 64 x 128
 }
 
 // ------------------------------------------------------------------------------------
