@@ -162,12 +162,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_x3_kernel(ConvParams p) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * MT) : "memory");
     __builtin_amdgcn_s_barrier();
     run_tap(cur, g, 0);
-    issue_dma(g + 1, nxt);  // the other buffer was last read in chunk g-1, which every wave left before the barrier above
+    if (g + 1 < nchunks) issue_dma(g + 1, nxt);  // the other buffer was last read in chunk g-1, which every wave left before the barrier above
     for (int tap = 1; tap < p.ntap; ++tap) run_tap(cur, g, tap);
   };
-  const int bufsz = 12 * XW;
+  const int bufsz = 12 * XW;  // (a conv of at most 32 input channels has one chunk and is given one buffer: twice the workgroups per CU)
   for (int g = 0; g < nchunks; ++g) chunk_step(g, Xq + (g & 1) * bufsz, Xq + ((g + 1) & 1) * bufsz);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus copy of the last iteration, before the workgroup's LDS is released
 
   conv_epilogue<MT, NT>(p, acc, m0 + wm * (32 * MT), q0 + wn * (32 * NT), b, phase, l31, lh);
 }
@@ -181,7 +180,7 @@ static int launch_x3_cfg(const ConvParams& p0, hipStream_t st) {
   IX_ARG(p.Cout_pad % BM == 0 && p.Cout_pad >= p.m_tiles * BM, "conv_x3: Cout_pad %d not a multiple of BM %d", p.Cout_pad, BM);
   const int adil = p.dil < 0 ? -p.dil : p.dil;
   const int XW = BN + (p.ntap - 1) * adil;
-  const size_t smem = (size_t)2 * 12 * XW * 16;  // two x-tile buffers of 12 rows
+  const size_t smem = (size_t)(p.Cin_pad > 32 ? 2 : 1) * 12 * XW * 16;  // two x-tile buffers of 12 rows (one when there is a single chunk)
   IX_ARG(smem <= 160 * 1024, "conv_x3: LDS tile %zu B too large", smem);
   auto kern = conv1d_x3_kernel<MT, NT, WM, WN>;
   if (smem > 64 * 1024) {
@@ -205,7 +204,7 @@ int conv_x3_cout_pad(int Cout) { return Cout <= 32 ? 32 : Cout <= 64 ? 64 : (Cou
 // (tile quantisation in both directions) x a mild preference for the bigger tile (fewer L2 bytes per flop).
 static double x3_tile_score(const ConvParams& p, int BM, int BN, int max_occ, double pref) {
   const int adil = p.dil < 0 ? -p.dil : p.dil;
-  const size_t smem = (size_t)2 * 12 * (BN + (p.ntap - 1) * adil) * 16;
+  const size_t smem = (size_t)(p.Cin_pad > 32 ? 2 : 1) * 12 * (BN + (p.ntap - 1) * adil) * 16;
   const int occ = std::max(1, std::min(max_occ, (int)((160 * 1024) / (smem + 512))));
   const double wgs = (double)ceil_div(p.Cout, BM) * ceil_div(p.Nq, BN) * p.B * p.nphase;
   const double slots = 256.0 * occ;
