@@ -5,7 +5,9 @@ Default workload (BASELINE configs[1], SURVEY.md 8(d) "Config 2"): ONE /tts requ
 2 segments x 100 tokens (prompt P = 137 rows), 5 s speaker prompt -> the conditioning encoders (conformer + perceiver, torch
 glue) -> greedy fixed-length decode of n = 1100 codes per segment, both segments decoded together (stop token suppressed:
 random weights never emit EOS) -> the latent GPT forward per segment -> s2mel (length regulator + 25-step CFM/DiT, torch glue
-with HIP attention / row kernels) -> BigVGAN over floor(1.72 n) = 1892 mel frames per segment -> 44.13 s of audio.  ALL of
+with HIP attention / row kernels) -> BigVGAN over floor(1.72 n) = 1892 mel frames per segment -> 44.13 s of audio.  (s2mel and
+BigVGAN are fp32 end to end; their attention / conv products run as six exact bf16 MFMA partial products per fp32 product with fp32
+accumulation, DESIGN.md 4.4 -- IXTTS_ATTN_FULL=f32 / IXTTS_BV_CONV=f32 select the fp32-MFMA kernels.)  ALL of
 these stages are inside the timed region; what stays synthetic is what the reference caches per speaker prompt (w2v-bert
 features, CAM++ style, prompt condition, reference mel): seeded HBM-resident tensors of the production shapes.
 
