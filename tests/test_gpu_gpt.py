@@ -172,6 +172,39 @@ def test_sampling_distribution_vs_oracle(tiny_f32):
             assert len(counts) > 1 or ref[top] > 0.97
 
 
+def test_top_k_when_one_thread_holds_the_large_scores(dev):
+    """`topk_sorted_1024` bounds the k-th largest score by the k-th largest per-thread maximum; a thread owns the tokens t, t + 1024,
+    ... -- with the 30 largest logits placed on 4 threads (and with every logit equal) the candidate pool degenerates and the
+    kernel must take its exact four-pass select.  Probabilities against the oracle's processors either way."""
+    import voice_tts_amd.weights as WR
+    from oracle import gpt as OG
+    from voice_tts_amd.gpt_engine import GptEngine
+
+    cfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2)
+    W = WR.make_gpt_weights(cfg, seed=5)
+    W["mel_head.weight"] = torch.zeros_like(W["mel_head.weight"])  # logits = the head's bias, whatever the hidden state
+    g = torch.Generator().manual_seed(6)
+    emb = torch.randn(20, 128, generator=g) * 0.5
+    for case in ("clustered", "flat"):
+        bias = torch.randn(8194, generator=g) * 0.1 if case == "clustered" else torch.zeros(8194)
+        if case == "clustered":
+            big = [t + 1024 * i for t in (5, 6, 7, 700) for i in range(8)]  # 32 large values on four threads
+            bias[big] = 8.0 + torch.rand(len(big), generator=g)
+        W["mel_head.bias"] = bias
+        eng = GptEngine(cfg, dtype="f32", max_seq=64, max_batch=1, device=dev).load_state_dict(W)
+        eng.prefill(0, emb, 0)
+        eng.decode(1, 1, repetition_penalty=1.0, temperature=0.9, top_k=30, top_p=1.0, do_sample=True, seed=3)
+        ids, _ = eng.read(0)
+        probs = eng.read_probs(0)
+        if case == "clustered":
+            ref = torch.softmax(OG.process_logits(bias.clone(), [], 1.0, 0.9, 30, 1.0, 1), -1).numpy()
+            assert np.abs(probs - ref).max() <= 1e-5 and (probs > 0).sum() == 30
+            assert ref[int(ids[0])] > 0
+        else:  # every token ties with the k-th: HF keeps them all; the device keeps its 128-entry survivor list, uniformly
+            kept = probs[probs > 0]
+            assert len(kept) == 128 and np.allclose(kept, 1.0 / 128, rtol=1e-5) and probs[int(ids[0])] > 0
+
+
 def test_sampling_with_unbounded_top_k_vs_oracle(tiny_f32):
     """G8 corners generate() reaches through infer(top_k=..., top_p=...): top_k = 0 (off), top_k beyond the 128-entry survivor
     list, top_p = 1.0, a top_p that leaves only min_tokens_to_keep.  The device's processed probability vector equals the
