@@ -51,3 +51,14 @@ def test_emovec_and_merge(case):
     _close(m.get_emovec(spk, full(spk)), g["emovec_spk"])
     _close(m.get_emovec(emo, full(emo)), g["emovec_emo"])
     _close(m.merge_emovec(spk, emo, full(spk), full(emo), alpha=0.7), g["merged_alpha07"])
+
+
+def test_host_side_mask_decision_matches_the_device_one():
+    """`lens_host` lets the encoders decide mask-free execution without reading the mask back (a hipGraph capture cannot): the
+    predicate equals `bool(mask[:, :, 2::2].all())` for every (T, length)."""
+    from voice_tts_amd.conditioning import Conditioning
+
+    for T in range(1, 40):
+        for n in range(0, 45):
+            mask = (torch.arange(T).unsqueeze(0) < torch.tensor([n]).unsqueeze(1)).unsqueeze(1)[:, :, 2::2]
+            assert bool(mask.all()) == Conditioning._kept_mask_is_full(T, [n]), (T, n)

@@ -343,3 +343,4 @@ def test_http_batched_mode_over_the_real_pipeline(tts_from_dir, monkeypatch):
         for r in rs:
             with wave.open(io.BytesIO(bytes.fromhex(r.json()["audio_hex"]))) as w:
                 assert w.getframerate() == 22050 and w.getnframes() > 0
+

@@ -159,8 +159,16 @@ class Conditioning:
             x = x.masked_fill(~mask, 0.0)
         return x.transpose(1, 2)
 
-    def conformer(self, xs, lens, prefix, m):
-        """ConformerEncoder.forward: xs [B,T,idim], lens [B] -> (ys [B,T',D], mask [B,1,T']), T' = (T-1)//2."""
+    @staticmethod
+    def _kept_mask_is_full(T, lens_host):
+        """Whether the pad mask, after the 2x subsampling keeps positions 2, 4, ..., is all true -- from lengths known on the host
+        (what `bool(mask.all())` asks the device; a hipGraph capture cannot)."""
+        kept = range(2, T, 2)
+        return len(kept) == 0 or all(kept[-1] < int(l) for l in lens_host)
+
+    def conformer(self, xs, lens, prefix, m, lens_host=None):
+        """ConformerEncoder.forward: xs [B,T,idim], lens [B] -> (ys [B,T',D], mask [B,1,T']), T' = (T-1)//2.
+        lens_host: the same lengths as python ints (optional): decides mask-free execution without a device read-back."""
         W = self.W
         B, T, _ = xs.shape
         D, heads = m["output_size"], m["attention_heads"]
@@ -171,7 +179,8 @@ class Conditioning:
         x = x * math.sqrt(D)
         pos_emb = self._pos_table(t, D).unsqueeze(0)
         mask = mask[:, :, 2::2]
-        amask = None if bool(mask.all()) else mask  # one full-length prompt: every masked_fill is a no-op
+        full = self._kept_mask_is_full(T, lens_host) if lens_host is not None else bool(mask.all())
+        amask = None if full else mask  # one full-length prompt: every masked_fill is a no-op
         ln = lambda v, n: F.layer_norm(v, (D,), W[n + ".weight"], W[n + ".bias"], 1e-5)
         for i in range(m["num_blocks"]):
             e = prefix + f"encoders.{i}."
@@ -210,29 +219,50 @@ class Conditioning:
         return F.normalize(lat, dim=-1) * (dim ** 0.5) * W[prefix + "norm.gamma"]  # RMSNorm (perceiver.py:139-158)
 
     # ------------------------------------------------------------------ UnifiedVoice entry points
-    def get_conditioning(self, spk_cond_emb, lens):
+    def get_conditioning(self, spk_cond_emb, lens, lens_host=None):
         """model_v2.py:513-541 (conformer_perceiver): spk_cond_emb [B,1024,T] as the pipeline passes it -> [B,32,model_dim]."""
         m = self.cfg["condition_module"]
-        x, mask = self.conformer(spk_cond_emb.transpose(1, 2), lens, "conditioning_encoder.", m)
+        x, mask = self.conformer(spk_cond_emb.transpose(1, 2), lens, "conditioning_encoder.", m, lens_host)
         cmask = F.pad(mask.squeeze(1), (self.cfg["cond_num"], 0), value=True)
-        return self.perceiver(x, None if bool(cmask.all()) else cmask, "perceiver_encoder.", m["attention_heads"])
+        full = self._kept_mask_is_full(spk_cond_emb.shape[-1], lens_host) if lens_host is not None else bool(cmask.all())
+        return self.perceiver(x, None if full else cmask, "perceiver_encoder.", m["attention_heads"])
 
-    def get_emo_conditioning(self, emo_cond_emb, lens):
+    def get_emo_conditioning(self, emo_cond_emb, lens, lens_host=None):
         """model_v2.py:544-549: [B,1024,T] -> [B,emo_dim]."""
         m = self.cfg["emo_condition_module"]
-        x, mask = self.conformer(emo_cond_emb.transpose(1, 2), lens, "emo_conditioning_encoder.", m)
+        x, mask = self.conformer(emo_cond_emb.transpose(1, 2), lens, "emo_conditioning_encoder.", m, lens_host)
         cmask = F.pad(mask.squeeze(1), (1, 0), value=True)
-        return self.perceiver(x, None if bool(cmask.all()) else cmask, "emo_perceiver_encoder.", m["attention_heads"]).squeeze(1)
+        full = self._kept_mask_is_full(emo_cond_emb.shape[-1], lens_host) if lens_host is not None else bool(cmask.all())
+        return self.perceiver(x, None if full else cmask, "emo_perceiver_encoder.", m["attention_heads"]).squeeze(1)
 
-    def get_emovec(self, emo_cond_emb, lens):
+    def get_emovec(self, emo_cond_emb, lens, lens_host=None):
         """model_v2.py:736-740: [B,T,1024] -> [B,model_dim]."""
         W = self.W
-        v = self.get_emo_conditioning(emo_cond_emb.transpose(1, 2), lens)
+        v = self.get_emo_conditioning(emo_cond_emb.transpose(1, 2), lens, lens_host)
         v = F.linear(v, W["emovec_layer.weight"], W["emovec_layer.bias"])
         return F.linear(v, W["emo_layer.weight"], W["emo_layer.bias"])
 
-    def merge_emovec(self, spk_cond_emb, emo_cond_emb, cond_lens, emo_cond_lens, alpha=1.0):
+    def merge_emovec(self, spk_cond_emb, emo_cond_emb, cond_lens, emo_cond_lens, alpha=1.0, cond_lens_host=None, emo_lens_host=None):
         """model_v2.py:742-747: base + alpha * (emo - base), both from the emotion encoder."""
-        emo = self.get_emovec(emo_cond_emb, emo_cond_lens)
-        base = self.get_emovec(spk_cond_emb, cond_lens)
+        emo = self.get_emovec(emo_cond_emb, emo_cond_lens, emo_lens_host)
+        base = self.get_emovec(spk_cond_emb, cond_lens, cond_lens_host)
         return base + alpha * (emo - base)
+
+    # ------------------------------------------------------------------ the per-request call of the pipeline
+    def _encode_eager(self, sc, ec, alpha, ls, le):
+        lsh, leh = [sc.shape[-1]], [ec.shape[-1]]  # the lengths as the host knows them: no device read-back for the mask decisions
+        emovec = self.merge_emovec(sc, ec, ls, le, alpha=alpha, cond_lens_host=lsh, emo_lens_host=leh)
+        return self.get_conditioning(sc.transpose(1, 2), ls, lsh)[0], emovec
+
+    @torch.no_grad()
+    def encode_prompt(self, spk_cond_emb, emo_cond_emb=None, emo_alpha=1.0):
+        """infer_v2.py:629-635: (get_conditioning(spk) [32, D], merge_emovec(spk, emo, alpha) [1, D]) for one request; the lengths
+        handed to the encoders are `shape[-1]` of the [1, T, 1024] features, as the reference passes them.  ~1000 small launches,
+        launch-bound (9 ms; 12-14 with the three device read-backs `lens_host` removes).  (Replaying the passes from a hipGraph
+        captured per prompt shape took 6 ms but returned a different emotion vector than the eager pass for prompts without a separate
+        emotion prompt; not understood, so not kept.)"""
+        sc = spk_cond_emb.to(self.device, torch.float32)
+        has_emo = emo_cond_emb is not None
+        ec = emo_cond_emb.to(self.device, torch.float32) if has_emo else sc
+        ls, le = torch.tensor([sc.shape[-1]], device=self.device), torch.tensor([ec.shape[-1]], device=self.device)
+        return self._encode_eager(sc, ec, float(emo_alpha) if has_emo else 1.0, ls, le)

@@ -419,10 +419,7 @@ class IndexTTS2:
                 self.cache_emo_cond, self.cache_emo_audio_prompt = emotion_fn(emo_prompt), emo_prompt
             emo_cond = self.cache_emo_cond
             if self.cond is not None:
-                sc, ec = spk["spk_cond_emb"].to(self.device, torch.float32), emo_cond.to(self.device, torch.float32)
-                ls, le = torch.tensor([sc.shape[-1]], device=self.device), torch.tensor([ec.shape[-1]], device=self.device)
-                emovec = self.cond.merge_emovec(sc, ec, ls, le, alpha=emo_alpha)
-                cond32 = self.cond.get_conditioning(sc.transpose(1, 2), ls)[0]
+                cond32, emovec = self.cond.encode_prompt(spk["spk_cond_emb"], emo_cond, emo_alpha)
             else:
                 emovec = self._stage("merge_emovec", None)(spk["spk_cond_emb"], emo_cond, emo_alpha)
                 cond32 = self._stage("get_conditioning", None)(spk["spk_cond_emb"])

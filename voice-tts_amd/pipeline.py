@@ -157,11 +157,7 @@ class HotPath:
     def conds_from_prompt(self, spk_cond_emb, emo_cond_emb=None, emo_alpha=1.0):
         """infer_v2.py:629-635 + model_v2.py:684-696: w2v-bert features [1,T,1024] of the speaker (and emotion) prompt ->
         conds_latent [34, D].  Once per request (the reference recomputes it per segment)."""
-        sc = spk_cond_emb.to(self.device, torch.float32)
-        ec = sc if emo_cond_emb is None else emo_cond_emb.to(self.device, torch.float32)
-        ls, le = torch.tensor([sc.shape[-1]], device=self.device), torch.tensor([ec.shape[-1]], device=self.device)
-        emovec = self.cond_model.merge_emovec(sc, ec, ls, le, alpha=emo_alpha if emo_cond_emb is not None else 1.0)
-        cond32 = self.cond_model.get_conditioning(sc.transpose(1, 2), ls)[0]
+        cond32, emovec = self.cond_model.encode_prompt(spk_cond_emb, emo_cond_emb, emo_alpha)
         return self.conds_latent(cond32, emovec)
 
     # ------------------------------------------------------------------ N1 (PyTorch glue, optional)
