@@ -251,7 +251,12 @@ class Conditioning:
     # ------------------------------------------------------------------ the per-request call of the pipeline
     def _encode_eager(self, sc, ec, alpha, ls, le):
         lsh, leh = [sc.shape[-1]], [ec.shape[-1]]  # the lengths as the host knows them: no device read-back for the mask decisions
-        emovec = self.merge_emovec(sc, ec, ls, le, alpha=alpha, cond_lens_host=lsh, emo_lens_host=leh)
+        if ec is sc:
+            # no separate emotion prompt: merge_emovec(spk, spk, alpha) = base + alpha * (base - base) = base, bit for bit -- one pass
+            # through the emotion encoder instead of two identical ones
+            emovec = self.get_emovec(sc, ls, lsh)
+        else:
+            emovec = self.merge_emovec(sc, ec, ls, le, alpha=alpha, cond_lens_host=lsh, emo_lens_host=leh)
         return self.get_conditioning(sc.transpose(1, 2), ls, lsh)[0], emovec
 
     @torch.no_grad()

@@ -410,6 +410,7 @@ class IndexTTS2:
                 scale = max(0.0, min(1.0, emo_alpha))
                 if scale != 1.0:
                     emo_vector = [int(x * scale * 10000) / 10000 for x in emo_vector]
+            emo_is_spk = emo_prompt is None  # (then both emotion-encoder passes see the same features: computed once)
             if emo_prompt is None:
                 emo_prompt, emo_alpha = spk_prompt, 1.0
             if self.cache_spk is None or not _same_prompt(self.cache_spk_audio_prompt, spk_prompt):
@@ -419,7 +420,7 @@ class IndexTTS2:
                 self.cache_emo_cond, self.cache_emo_audio_prompt = emotion_fn(emo_prompt), emo_prompt
             emo_cond = self.cache_emo_cond
             if self.cond is not None:
-                cond32, emovec = self.cond.encode_prompt(spk["spk_cond_emb"], emo_cond, emo_alpha)
+                cond32, emovec = self.cond.encode_prompt(spk["spk_cond_emb"], None if emo_is_spk else emo_cond, emo_alpha)
             else:
                 emovec = self._stage("merge_emovec", None)(spk["spk_cond_emb"], emo_cond, emo_alpha)
                 cond32 = self._stage("get_conditioning", None)(spk["spk_cond_emb"])
