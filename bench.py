@@ -368,9 +368,16 @@ def main():
         step = lambda acc: run_request(wl, hp, pr, texts, n_codes, args.decode, R, acc)
 
     scratch = dict(wl.stage_ms)
+    first_request_s = None
     for i in range(args.warmup):
-        step(dict(scratch))
-        log(f"warmup {i} done")
+        acc_w = dict(scratch)
+        tw = time.perf_counter()
+        step(acc_w)
+        torch.cuda.synchronize()
+        tw = time.perf_counter() - tw
+        if i == 0:  # the first request of a fresh worker (graph capture, library / kernel-cache loads): reported, never timed
+            first_request_s = tw
+        log(f"warmup {i} done in {tw:.2f}s: " + ", ".join(f"{k} {v:.0f} ms" for k, v in acc_w.items()))
 
     def barrier():
         if dist is not None:
@@ -628,6 +635,7 @@ def main():
             },
             "stage_ms_per_step": {k: round(v / args.steps, 2) for k, v in stage_ms.items()},
             "load_s": round(t_load, 1),
+            "first_request_s": None if first_request_s is None else round(first_request_s, 2),
             "roofline": roofline,
             "stage_rooflines": stage_roof,
             "extra": extra,

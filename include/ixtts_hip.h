@@ -227,6 +227,24 @@ int ixtts_gpt_beam_read(ixtts_gpt* h, int max_new, int32_t* ids_host, int cap, i
 /* Parity-test hook: the NEXT beam step uses these 2*num_beams flat draws (beam*V + token) instead of sampling. */
 int ixtts_gpt_beam_force(ixtts_gpt* h, const int32_t* picks_host, int n, void* stream);
 
+/* Beam GROUPS: the reference runs `inference_speech` once per text segment, one after another (infer_v2.py:616-658), each a
+ * `_beam_search` over num_beams sequences.  Here the segments of a request (or of several requests) decode TOGETHER: group g
+ * owns slots g*num_beams .. g*num_beams+num_beams-1 and its own scorer state (beam scores, hypotheses, done flag, forced
+ * draws), the weights are read once per step for all groups.  An engine of up to 4 slots holds one group (the calls above ==
+ * group 0); a wide engine (max_batch 5..16, bf16) holds floor(max_batch / num_beams) of them.  A group's tokens do not depend
+ * on which other groups step with it.  Usage per segment: ixtts_gpt_prefill(h, g*num_beams, ...) ->
+ * ixtts_gpt_beam_begin_group(h, g, num_beams, rng_stream) (rng_stream selects the group's random stream: 0 is the stream
+ * ixtts_gpt_beam_begin uses, so segment i decoded with rng_stream i draws the same numbers in any group) -> repeated
+ * ixtts_gpt_beam_decode_groups(h, n_groups, n_steps, cfg) stepping groups 0..n_groups-1 (finished or parked groups inside
+ * that range are no-ops) -> ixtts_gpt_beam_read_group.  ixtts_gpt_beam_park_group takes a group out of the stepping set
+ * until its next begin (its slots keep running through the layers with their last token; nothing is read from them). */
+int ixtts_gpt_beam_begin_group(ixtts_gpt* h, int group, int num_beams, uint64_t rng_stream, void* stream);
+int ixtts_gpt_beam_park_group(ixtts_gpt* h, int group, void* stream);
+int ixtts_gpt_beam_decode_groups(ixtts_gpt* h, int n_groups, int n_steps, const ixtts_sampler_cfg* sc, void* stream);
+int ixtts_gpt_beam_read_group(ixtts_gpt* h, int group, int max_new, int32_t* ids_host, int cap, int* n_ids, int* done, float* score,
+                              float* beam_scores_host, int32_t* last_tokens_host, int32_t* beam_idx_host, void* stream);
+int ixtts_gpt_beam_force_group(ixtts_gpt* h, int group, const int32_t* picks_host, int n, void* stream);
+
 /* `UnifiedVoice.forward(...)->get_logits(return_latent=True)` (model_v2.py:554-596,486-512):
  * prefix_dev [n_prefix, D] = [conds 34 ; text_emb L+2] rows; codes_dev [n] int32 mel codes.
  * Embeds [start, codes, stop] with mel positions 0..n+1, runs the full causal trunk,

@@ -150,6 +150,18 @@ class GptOracle:
         h, past = self.trunk(emb, past, km)
         return self.head(h[:, -1])[0], past
 
+    def decode_step_batch(self, tokens, k, past, mask_prefix):
+        """`decode_step` for B sequences that share the prompt mask and sit at the same step k (the beams of one
+        `_beam_search`, model_v2.py:156-160 with input_ids [B, 1]); past: list of (k, v) each [B,H,S,dh].
+        Returns (logits [B,V], past)."""
+        W = self.W
+        tok = torch.as_tensor(tokens, dtype=torch.long)
+        emb = (W["mel_embedding.weight"][tok] + W["mel_pos_embedding.emb.weight"][k + 1]).unsqueeze(1)
+        S = past[0][0].shape[2]
+        km = torch.cat((torch.as_tensor(mask_prefix).view(1, -1), torch.ones(1, S + 1 - len(mask_prefix), dtype=torch.long)), dim=1)
+        h, past = self.trunk(emb, past, km.expand(tok.numel(), -1))
+        return self.head(h[:, -1]), past
+
     # -------------------------------------------------------- latent pass (G9)
     def latent_pass(self, conds_latent, text_ids, codes, start_text=0, stop_text=1, start_mel=8192, stop_mel=8193):
         """UnifiedVoice.forward(...)->get_logits(return_latent=True) (model_v2.py:554-596,486-512).
@@ -367,22 +379,28 @@ def beam_finalize(hyps, done, histories, beam_scores, eos, max_new):
     return seq, best[0]
 
 
-def beam_scores_step(logits_rows, histories_full, beam_scores, theta, temperature, top_k, top_p):
-    """log_softmax -> processors (min_tokens_to_keep = 2) -> + beam score (generation_utils.py:3473-3481)."""
+def beam_scores_step(logits_rows, histories_full, beam_scores, theta, temperature, top_k, top_p, suppress=None):
+    """log_softmax -> processors (min_tokens_to_keep = 2) -> + beam score (generation_utils.py:3473-3481).
+    `suppress` (bench-only fixed-length mode): those ids' log-probabilities forced to -inf before the processors."""
     rows = []
     for b in range(len(beam_scores)):
         lp = torch.log_softmax(logits_rows[b].to(torch.float32), dim=-1)
-        s = process_logits(lp, histories_full[b], theta, temperature, top_k, top_p, min_keep=2)
+        s = process_logits(lp, histories_full[b], theta, temperature, top_k, top_p, min_keep=2, suppress=suppress)
         rows.append(s + beam_scores[b])
     return torch.stack(rows)  # [num_beams, V]
 
 
 def generate_beam_sample(oracle, embeds, mask, max_new, num_beams=3, theta=10.0, temperature=0.8, top_k=30, top_p=0.8,
-                         stop_mel=8193, start_mel=8192, sampler=None, generator=None, trace=None, length_penalty=0.0):
+                         stop_mel=8193, start_mel=8192, sampler=None, generator=None, trace=None, length_penalty=0.0,
+                         batched=False, suppress_stop=False, keep_logits=None):
     """`_beam_search` with do_sample=True (generation_utils.py:3406-3565): the served default.
 
     `sampler(scores_flat[num_beams*V]) -> 2*num_beams flat indices` lets a test force the draws;
     default = softmax + torch.multinomial without replacement.
+    `batched`: the beams step through the trunk as one batch (as the reference does: input_ids [num_beams, 1], the cache
+    reordered by index_select, model_v2.py:199-212) instead of one by one -- the production-width tests use it, the weights
+    being read once per step; tests/test_oracle_golden.py holds the two forms to each other.
+    `keep_logits`: steps s whose per-beam logits (the distributions step s + 1 draws from) go into trace[s - 1]["logits"].
     """
     P = len(mask)
     prefix = [1] * (P - 1) + [start_mel]
@@ -390,11 +408,14 @@ def generate_beam_sample(oracle, embeds, mask, max_new, num_beams=3, theta=10.0,
     V = logits0.numel()
     logits = [logits0.clone() for _ in range(num_beams)]
     pasts = [past0 for _ in range(num_beams)]
+    if batched:
+        pasts = [(k.expand(num_beams, -1, -1, -1), v.expand(num_beams, -1, -1, -1)) for k, v in past0]
     hist = [[] for _ in range(num_beams)]
     beam_scores = [0.0] + [-1e9] * (num_beams - 1)
     hyps, done = BeamHyps(num_beams, length_penalty), False
     for step in range(1, max_new + 1):
-        scores = beam_scores_step(logits, [prefix + h for h in hist], beam_scores, theta, temperature, top_k, top_p)
+        scores = beam_scores_step(logits, [prefix + h for h in hist], beam_scores, theta, temperature, top_k, top_p,
+                                  suppress=[stop_mel] if suppress_stop else None)
         flat = scores.reshape(-1)
         if sampler is not None:
             picks = sampler(flat, step)
@@ -411,14 +432,51 @@ def generate_beam_sample(oracle, embeds, mask, max_new, num_beams=3, theta=10.0,
             trace.append(dict(picks=picks.tolist(), scores=sc.tolist(), next_scores=list(ns), next_tokens=list(nt), next_indices=list(ni), done=done))
         hist = [hist[ni[j]] + [nt[j]] for j in range(num_beams)]
         beam_scores = list(ns)
-        pasts = [pasts[ni[j]] for j in range(num_beams)]
         if done or step == max_new:
             break
-        new_logits, new_pasts = [], []
-        for j in range(num_beams):
-            lg, pj = oracle.decode_step(nt[j], step, pasts[j], mask)
-            new_logits.append(lg)
-            new_pasts.append(pj)
-        logits, pasts = new_logits, new_pasts
+        if batched:
+            idx = torch.as_tensor(ni, dtype=torch.long)
+            lg, pasts = oracle.decode_step_batch(nt, step, [(k.index_select(0, idx), v.index_select(0, idx)) for k, v in pasts], mask)
+            logits = [lg[j] for j in range(num_beams)]
+        else:
+            pasts = [pasts[ni[j]] for j in range(num_beams)]
+            new_logits, new_pasts = [], []
+            for j in range(num_beams):
+                lg, pj = oracle.decode_step(nt[j], step, pasts[j], mask)
+                new_logits.append(lg)
+                new_pasts.append(pj)
+            logits, pasts = new_logits, new_pasts
+        if trace is not None and keep_logits is not None and step in keep_logits:
+            trace[-1]["logits"] = torch.stack(list(logits)).clone()
     seq, score = beam_finalize(hyps, done, hist, beam_scores, stop_mel, max_new)
     return seq, score
+
+
+def beam_replay(oracle, embeds, mask, step_tokens, step_src, theta=10.0, temperature=0.8, top_k=30, top_p=0.8, stop_mel=8193,
+                start_mel=8192, suppress_stop=False, keep_logits=()):
+    """A GIVEN beam-sample run (per step: the token each new beam took and the beam it continues) pushed through the oracle:
+    what `_beam_search` would have scored it.  Returns a list with, per step, `inc` [num_beams] = the processed log-probability
+    of (source beam, token) -- the beam score's increment (-inf where the oracle's TopK / TopP removed that token), `kept`
+    [num_beams] bools, and `logits` [num_beams, V] after the steps in `keep_logits`.  The beams step as one batch."""
+    P = len(mask)
+    prefix = [1] * (P - 1) + [start_mel]
+    nb = len(step_tokens[0])
+    logits0, past0 = oracle.prefill(embeds, mask, start_mel)
+    logits = [logits0.clone() for _ in range(nb)]
+    pasts = [(k.expand(nb, -1, -1, -1), v.expand(nb, -1, -1, -1)) for k, v in past0]
+    hist = [[] for _ in range(nb)]
+    out = []
+    for step, (toks, src) in enumerate(zip(step_tokens, step_src), start=1):
+        toks, src = [int(t) for t in toks], [int(b) for b in src]
+        scores = beam_scores_step(logits, [prefix + h for h in hist], [0.0] * nb, theta, temperature, top_k, top_p,
+                                  suppress=[stop_mel] if suppress_stop else None)
+        inc = [float(scores[src[j], toks[j]]) for j in range(nb)]
+        rec = dict(inc=inc, kept=[v != float("-inf") for v in inc])
+        hist = [hist[src[j]] + [toks[j]] for j in range(nb)]
+        idx = torch.as_tensor(src, dtype=torch.long)
+        lg, pasts = oracle.decode_step_batch(toks, step, [(k.index_select(0, idx), v.index_select(0, idx)) for k, v in pasts], mask)
+        logits = [lg[j] for j in range(nb)]
+        if step in keep_logits:
+            rec["logits"] = lg.clone()
+        out.append(rec)
+    return out

@@ -94,30 +94,31 @@ def bench_prompts(gpt_full):
     return out
 
 
-def _run_bench_shape(W, prompts, dtype, dev):
-    """Free-running greedy decode exactly as bench.py issues it (B=2, repetition penalty 10, stop suppressed), cut into
-    chunks so the logits can be read at: step 1, 2, around every 256-key bucket boundary of either slot, and step 1100."""
+def _run_bench_shape(W, prompts, dtype, dev, n=N_BENCH):
+    """Free-running greedy decode exactly as bench.py issues it (B = len(prompts), repetition penalty 10, stop suppressed), cut
+    into chunks so the logits can be read at: step 1, 2, around every 256-key bucket boundary of any slot, and step n."""
     import voice_tts_amd.weights as WR
     from voice_tts_amd.gpt_engine import GptEngine
 
-    eng = GptEngine(WR.GPT_CFG, dtype=dtype, max_seq=137 + N_BENCH + 64, max_batch=2, device=dev).load_state_dict(W)
+    B = len(prompts)
+    eng = GptEngine(WR.GPT_CFG, dtype=dtype, max_seq=137 + n + 64, max_batch=B, device=dev).load_state_dict(W)
     for b, (emb, mask, pad) in enumerate(prompts):
         eng.prefill(b, emb, pad)
-    stops = {1, 2, 64, N_BENCH}
+    stops = {1, 2, 64, n}
     for _, mask, _ in prompts:
         for m in range(1, 6):
             for d in (-2, -1, 0, 1):
                 k = 256 * m - len(mask) + d
-                if 1 <= k <= N_BENCH:
+                if 1 <= k <= n:
                     stops.add(k)
-    got = {0: [eng.read_logits(b).copy() for b in range(2)]}
+    got = {0: [eng.read_logits(b).copy() for b in range(B)]}
     done = 0
     for k in sorted(stops):
-        eng.decode(2, k - done, repetition_penalty=10.0, suppress_stop=True)
+        eng.decode(B, k - done, repetition_penalty=10.0, suppress_stop=True)
         done = k
-        got[k] = [eng.read_logits(b).copy() for b in range(2)]
-    ids = [eng.read(b)[0][:N_BENCH] for b in range(2)]
-    assert all(len(i) == N_BENCH for i in ids)
+        got[k] = [eng.read_logits(b).copy() for b in range(B)]
+    ids = [eng.read(b)[0][:n] for b in range(B)]
+    assert all(len(i) == n for i in ids)
     return ids, got
 
 
@@ -172,6 +173,236 @@ def test_bench_shape_bf16_1100_steps_vs_oracle(gpt_full, bench_prompts, dev):
               f"raw top-1 agreement at read points {top1:.3f}")
         assert max(errs.values()) <= 1.5e-2, (b, errs)
         assert agree >= 0.95, (b, agree)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# B and K are template parameters of the register GEMVs: the 3- and 4-sequence instantiations (3 = the beams of the served
+# default) at 24 layers x D=1280, free-running greedy as above, against ONE causal oracle pass per slot.  400 steps from prompts
+# of 137 / 117 (3 padded) / 97 / 127 (1 padded) rows: every slot crosses the 256-key bucket, the longer ones the 512-key one.
+N_B34 = 400
+
+
+@pytest.fixture(scope="module")
+def prompts_b34(gpt_full, bench_prompts):
+    orc = gpt_full[1]
+    g = torch.Generator().manual_seed(101)
+    out = list(bench_prompts)
+    for text in (torch.randint(2, 12000, (60,), generator=g), torch.cat((torch.tensor([1]), torch.randint(2, 12000, (89,), generator=g)))):
+        conds = torch.randn(34, 1280, generator=g) * 0.5
+        fake, embeds, mask = orc.prepare_gpt_inputs(conds, text)
+        out.append((embeds, mask, int((mask == 0).sum())))
+    assert [len(m) for _, m, _ in out] == [137, 117, 97, 127] and [p for _, _, p in out] == [0, 3, 0, 1]
+    return out
+
+
+@pytest.mark.parametrize("B", [3, 4])
+def test_register_gemv_b3_b4_fp32_vs_oracle(gpt_full, prompts_b34, dev, B):
+    W, orc = gpt_full[0], gpt_full[1]
+    prompts = prompts_b34[:B]
+    ids, got = _run_bench_shape(W, prompts, "f32", dev, n=N_B34)
+    ref = _oracle_rows(orc, prompts, ids)
+    for b in range(B):
+        rows, picks, margins = ref[b]
+        scale = float(rows.abs().max())
+        worst = max(np.abs(got[k][b] - rows[k].numpy()).max() for k in got) / scale
+        wrong = [k for k in range(N_B34) if picks[k] != int(ids[b][k]) and margins[k] >= 1e-4 * scale]
+        print(f"fp32 B={B} slot {b}: logits rel err {worst:.2e} over {len(got)} read points, {sum(int(picks[k] != int(ids[b][k])) for k in range(N_B34))} differing tokens")
+        assert worst <= 3e-4, (B, b, worst)
+        assert not wrong, (B, b, wrong[:5])
+
+
+@pytest.mark.parametrize("B", [3, 4])
+def test_register_gemv_b3_b4_bf16_vs_oracle(gpt_full, prompts_b34, dev, B):
+    W, orc = gpt_full[0], gpt_full[1]
+    prompts = prompts_b34[:B]
+    ids, got = _run_bench_shape(W, prompts, "bf16", dev, n=N_B34)
+    ref = _oracle_rows(orc, prompts, ids)
+    for b in range(B):
+        rows, picks, margins = ref[b]
+        scale = float(rows.abs().max())
+        errs = {k: np.abs(got[k][b] - rows[k].numpy()).max() / scale for k in got}
+        agree = sum(int(picks[k] == int(ids[b][k])) for k in range(N_B34)) / N_B34
+        print(f"bf16 B={B} slot {b}: logits rel err max {max(errs.values()):.2e}, greedy agreement {agree:.4f}")
+        assert max(errs.values()) <= 1.5e-2, (B, b, errs)
+        assert agree >= 0.95, (B, b, agree)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The served default at production width (infer_v2.py:598-606: num_beams=3 beam-sample, top_k 30, top_p 0.8, T 0.8, theta 10):
+# `_beam_search` (transformers_generation_utils.py:3406-3565) + `BeamSearchScorer.process` (transformers_beam_search.py:215-318)
+# + `_reorder_cache` over 24 layers x 20 heads (model_v2.py:199-212), P = 137, context 137 -> 441 (the split-S attention switches
+# its 256-key bucket at step 118).
+N_BEAM = 304
+BEAM_READS = (1, 2, 116, 117, 118, 119, 120, 121, 200, N_BEAM - 1)
+
+
+@pytest.fixture(scope="module")
+def beam_oracle_run(gpt_full, bench_prompts):
+    """The oracle's own 3-beam run (torch.multinomial draws from a seeded generator), every step recorded."""
+    from oracle import gpt as OG
+
+    W, orc = gpt_full[0], gpt_full[1]
+    emb, mask, pad = bench_prompts[0]
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    tr = []
+    seq, score = OG.generate_beam_sample(orc, emb, mask, N_BEAM, generator=torch.Generator().manual_seed(21), trace=tr, batched=True,
+                                         suppress_stop=True, keep_logits=set(BEAM_READS))
+    assert len(tr) == N_BEAM and not tr[-1]["done"]
+    return tr, seq, score
+
+
+def test_beam3_fp32_forced_draws_vs_oracle_full_size(gpt_full, bench_prompts, beam_oracle_run, dev):
+    """fp32 (parity mode), the oracle's draws forced step by step (`ixtts_gpt_beam_force`): every step's tokens and source
+    beams exact, beam scores within 2e-3 (+1e-4 relative), the logits of every beam at the read points -- both sides of the
+    bucket switch, i.e. after the 24-layer K/V reorder has moved rows -- within 3e-4 of the logit scale, final sequence equal."""
+    import voice_tts_amd.weights as WR
+    from voice_tts_amd.gpt_engine import GptEngine
+
+    W = gpt_full[0]
+    emb, mask, pad = bench_prompts[0]
+    tr, seq, score = beam_oracle_run
+    eng = GptEngine(WR.GPT_CFG, dtype="f32", max_seq=137 + N_BEAM + 64, max_batch=3, device=dev).load_state_dict(W)
+    eng.prefill(0, emb, pad)
+    eng.beam_begin(3)
+    worst_l, worst_s, moved = 0.0, 0.0, 0
+    for step, t in enumerate(tr, start=1):
+        eng.beam_force(t["picks"])
+        eng.beam_decode(1, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=True)
+        ids, done, sc, bs, lt, src = eng.beam_read(N_BEAM)
+        assert lt.tolist() == t["next_tokens"], step
+        assert src.tolist() == t["next_indices"], step
+        assert np.allclose(bs, t["next_scores"], rtol=1e-4, atol=2e-3), (step, bs, t["next_scores"])
+        fin = np.isfinite(bs) & np.isfinite(np.array(t["next_scores"]))  # (step 1 can hold a -inf draw: fewer than 3 live candidates)
+        worst_s = max(worst_s, float(np.abs(bs[fin] - np.array(t["next_scores"])[fin]).max()))
+        moved += int(src.tolist() != [0, 1, 2])
+        if "logits" in t:
+            ref = t["logits"].numpy()
+            scale = float(np.abs(ref).max())
+            for b in range(3):
+                worst_l = max(worst_l, float(np.abs(eng.read_logits(b) - ref[b]).max()) / scale)
+    print(f"beam3 fp32: {N_BEAM} forced steps, {moved} with a non-identity beam_idx, beam score max|err| {worst_s:.2e}, logits rel err {worst_l:.2e}")
+    assert not done and moved >= 30  # (the K/V reorder really moved rows: 65 of 304 steps in the recorded run)
+    assert worst_l <= 3e-4, worst_l
+    assert ids.tolist() == seq and abs(sc - score) <= 2e-3 + 1e-4 * abs(score)
+
+
+def _beam_free_run(eng, groups, prompts, n, chunk, seed):
+    """Free-running beam-sample of `groups` groups together; returns per group the per-call (tokens, src, scores) and the
+    final (ids, score)."""
+    for g in range(groups):
+        eng.prefill(g * 3, prompts[g][0], prompts[g][2])
+        eng.beam_begin(3, group=g, rng_stream=g)
+    rec = [[] for _ in range(groups)]
+    for _ in range(0, n, chunk):
+        eng.beam_decode(chunk, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=True, seed=seed, groups=groups)
+        for g in range(groups):
+            ids, done, sc, bs, lt, src = eng.beam_read(n, group=g)
+            rec[g].append((lt.tolist(), src.tolist(), bs.copy(), ids.tolist(), sc))
+    return rec
+
+
+def _check_beam_run_against_oracle(orc, prompt, rec, logits_at, n, tag):
+    """A device beam run (per step: tokens, source beams, scores) replayed through the oracle (`beam_replay`): stated bf16
+    bounds -- logits within 1.5e-2 of the logit scale, >= 97 % of the chosen (beam, token) pairs inside the fp32 oracle's
+    processed support, score increments within 0.05 |inc| + 0.25 at >= 95 % of them (median <= 0.05)."""
+    from oracle import gpt as OG
+
+    emb, mask, pad = prompt
+    toks, srcs = [r[0] for r in rec], [r[1] for r in rec]
+    rep = OG.beam_replay(orc, emb, mask, toks, srcs, suppress_stop=True, keep_logits=set(logits_at))
+    prev = np.array([0.0, -1e9, -1e9])
+    kept, diffs, rel_ok = 0, [], 0
+    for step, (r, o) in enumerate(zip(rec, rep), start=1):
+        bs = r[2].astype(np.float64)
+        inc_dev = bs - prev[np.array(r[1])]
+        for j in range(3):
+            if bs[j] < -1e8:
+                continue  # (step 1: fewer than three live candidates)
+            if o["kept"][j]:
+                kept += 1
+                d = abs(inc_dev[j] - o["inc"][j])
+                diffs.append(d)
+                rel_ok += int(d <= 0.05 * abs(o["inc"][j]) + 0.25)
+            else:
+                diffs.append(np.inf)
+        prev = bs
+    total = len(diffs)
+    finite = np.array([d for d in diffs if np.isfinite(d)])
+    worst_l = 0.0
+    for k, lg in logits_at.items():
+        ref = rep[k - 1]["logits"].numpy()
+        scale = float(np.abs(ref).max())
+        worst_l = max(worst_l, max(float(np.abs(lg[b] - ref[b]).max()) / scale for b in range(3)))
+    print(f"beam3 bf16 {tag}: {n} steps, chosen pairs inside the oracle's support {kept}/{total}, increment |err| median {np.median(finite):.3e} "
+          f"p95 {np.quantile(finite, 0.95):.3e} max {finite.max():.3e}, within 0.05|inc|+0.25: {rel_ok}/{total}, logits rel err {worst_l:.2e}")
+    assert worst_l <= 1.5e-2, worst_l
+    assert kept >= 0.97 * total, (kept, total)
+    assert rel_ok >= 0.95 * total and np.median(finite) <= 0.05
+
+
+def test_beam3_bf16_register_engine_vs_oracle_full_size(gpt_full, bench_prompts, dev):
+    """The benchmarked beam mode on the register GEMVs (B = 3, bf16 weights + KV): free-running with its own draws, one step
+    per call so every step's (tokens, beam_idx, scores) is recorded, then the same run through the oracle; and the same seed
+    decoded in 8-step graphs (what the product issues) gives the same sequence and score bit for bit."""
+    import voice_tts_amd.weights as WR
+    from voice_tts_amd.gpt_engine import GptEngine
+
+    W, orc = gpt_full[0], gpt_full[1]
+    eng = GptEngine(WR.GPT_CFG, dtype="bf16", max_seq=137 + N_BEAM + 64, max_batch=3, device=dev).load_state_dict(W)
+    emb, mask, pad = bench_prompts[0]
+    eng.prefill(0, emb, pad)
+    eng.beam_begin(3)
+    rec, logits_at = [], {}
+    for step in range(1, N_BEAM + 1):
+        eng.beam_decode(1, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=True, seed=9)
+        ids, done, sc, bs, lt, src = eng.beam_read(N_BEAM)
+        rec.append((lt.tolist(), src.tolist(), bs.copy(), ids.tolist(), sc))
+        if step in BEAM_READS:
+            logits_at[step] = [eng.read_logits(b).copy() for b in range(3)]
+    _check_beam_run_against_oracle(orc, bench_prompts[0], rec, logits_at, N_BEAM, "register B=3")
+    eng.prefill(0, emb, pad)
+    eng.beam_begin(3)
+    eng.beam_decode(N_BEAM, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=True, seed=9)
+    ids8, _, sc8 = eng.beam_read(N_BEAM)[:3]
+    assert ids8.tolist() == rec[-1][3] and sc8 == rec[-1][4]
+
+
+N_BEAM_WIDE = 160
+
+
+def test_beam3_bf16_two_groups_wide_engine_vs_oracle_full_size(gpt_full, bench_prompts, dev):
+    """What `infer()` runs for a two-segment request: both segments' beam groups together on the wide engine (6 slots on the
+    bf16 matrix cores), prompts of 137 and 117 (3 padded) rows, each group held to the oracle as above; then the same two
+    segments in 8-step graphs, and each one ALONE in group 0, give the same sequences bit for bit."""
+    import voice_tts_amd.weights as WR
+    from voice_tts_amd.gpt_engine import GptEngine
+
+    W, orc = gpt_full[0], gpt_full[1]
+    n = N_BEAM_WIDE
+    eng = GptEngine(WR.GPT_CFG, dtype="bf16", max_seq=137 + n + 64, max_batch=6, device=dev).load_state_dict(W)
+    reads = (1, 2, 60, n - 1)
+    for g in range(2):
+        eng.prefill(g * 3, bench_prompts[g][0], bench_prompts[g][2])
+        eng.beam_begin(3, group=g, rng_stream=g)
+    rec, logits_at = [[], []], [{}, {}]
+    for step in range(1, n + 1):
+        eng.beam_decode(1, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=True, seed=9, groups=2)
+        for g in range(2):
+            ids, done, sc, bs, lt, src = eng.beam_read(n, group=g)
+            rec[g].append((lt.tolist(), src.tolist(), bs.copy(), ids.tolist(), sc))
+            if step in reads:
+                logits_at[g][step] = [eng.read_logits(g * 3 + b).copy() for b in range(3)]
+    for g in range(2):
+        _check_beam_run_against_oracle(orc, bench_prompts[g], rec[g], logits_at[g], n, f"wide engine, group {g} of 2")
+    together = _beam_free_run(eng, 2, bench_prompts, n, 32, seed=9)
+    for g in range(2):
+        assert together[g][-1][3] == rec[g][-1][3] and together[g][-1][4] == rec[g][-1][4], g
+        eng.prefill(0, bench_prompts[g][0], bench_prompts[g][2])
+        eng.beam_begin(3, group=0, rng_stream=g)
+        eng.beam_park(1)
+        eng.beam_decode(n, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=True, seed=9, groups=1)
+        ids1, _, sc1 = eng.beam_read(n, group=0)[:3]
+        assert ids1.tolist() == rec[g][-1][3] and sc1 == rec[g][-1][4], g
 
 
 def test_bigvgan_full_size_config5_mel(dev):

@@ -178,10 +178,13 @@ def test_typical_sampling_vs_reference_processor(golden, case, min_keep, mass):
 BEAM_TAGS = ["noeos", "mid", "mid2", "eos", "eos2", "lp1", "lpneg", "lp2noeos"]  # the last three: length_penalty 1.0 / -0.7 / 2.0
 
 
+@pytest.mark.parametrize("batched", [False, True])
 @pytest.mark.parametrize("tag", BEAM_TAGS)
-def test_beam_sample_vs_reference_scorer(golden, tag):
+def test_beam_sample_vs_reference_scorer(golden, tag, batched):
     """3-beam beam-sample (the served default): oracle loop + scorer restatement vs a trace produced by
-    the reference's own BeamSearchScorer / HF processors / model forward, replaying the recorded draws."""
+    the reference's own BeamSearchScorer / HF processors / model forward, replaying the recorded draws.  `batched`: the
+    beams stepping through the trunk as one batch with an index_select-ed cache (the form the production-width GPU tests
+    use), held to the same reference trace."""
     g = golden("gpt_beam.npz")
     cfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2)
     W = WR.make_gpt_weights(cfg, seed=int(g["seed"]), head_scale=50.0)
@@ -192,7 +195,7 @@ def test_beam_sample_vs_reference_scorer(golden, tag):
     picks = g[f"{tag}_picks"]
     trace = []
     seq, score = OG.generate_beam_sample(orc, embeds, mask, int(g[f"{tag}_max_new"]), num_beams=3,
-                                         sampler=lambda flat, step: picks[step - 1], trace=trace,
+                                         sampler=lambda flat, step: picks[step - 1], trace=trace, batched=batched,
                                          length_penalty=float(g[f"{tag}_length_penalty"]) if f"{tag}_length_penalty" in g.files else 0.0)
     assert len(trace) == picks.shape[0]
     for t, ns, nt, ni in zip(trace, g[f"{tag}_next_scores"], g[f"{tag}_next_tokens"], g[f"{tag}_next_indices"]):
@@ -201,3 +204,26 @@ def test_beam_sample_vs_reference_scorer(golden, tag):
     assert trace[-1]["done"] == bool(g[f"{tag}_done"])
     assert seq == g[f"{tag}_sequence"].tolist()
     assert abs(score - float(g[f"{tag}_sequence_score"][0])) <= 1e-3 * max(1.0, abs(score))
+
+
+def test_beam_replay_scores_the_reference_trace(golden):
+    """`beam_replay` (a given run's per-step (token, source beam) pushed through the oracle -- what the bf16 production-width
+    GPU test holds the device's free-running beams to) on the reference's own trace: every step's tokens were inside the
+    processed support, and the accumulated increments are the reference's beam scores."""
+    g = golden("gpt_beam.npz")
+    tag = "noeos"
+    cfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2)
+    W = WR.make_gpt_weights(cfg, seed=int(g["seed"]), head_scale=50.0)
+    W["mel_head.bias"] = W["mel_head.bias"].clone()
+    W["mel_head.bias"][8193] += float(g[f"{tag}_stop_bias"])
+    orc = OG.GptOracle(W, cfg["layers"], cfg["heads"])
+    fake, embeds, mask = orc.prepare_gpt_inputs(torch.from_numpy(g[f"{tag}_conds_latent"]), g[f"{tag}_text"])
+    nt, ni, ns = g[f"{tag}_next_tokens"], g[f"{tag}_next_indices"], g[f"{tag}_next_scores"]
+    rep = OG.beam_replay(orc, embeds, mask, nt, ni, keep_logits={1, len(nt)})
+    score = np.array([0.0, -1e9, -1e9])
+    for step, r in enumerate(rep):
+        # (step 1 of the trace: beam 0 keeps two tokens, so the third draw of torch.multinomial is a zero-probability entry, score -inf)
+        assert r["kept"] == np.isfinite(ns[step]).tolist(), step
+        score = score[ni[step]] + np.array(r["inc"])
+        assert np.allclose(score, ns[step], rtol=1e-4, atol=1e-3), step
+    assert rep[0]["logits"].shape == (3, 8194) and "logits" not in rep[1]

@@ -76,6 +76,11 @@ SYMBOLS = {
     "ixtts_gpt_beam_decode": (C.c_int, [_P, C.c_int, C.POINTER(SamplerCfg), _P]),
     "ixtts_gpt_beam_read": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), _P, _P, _P, _P]),
     "ixtts_gpt_beam_force": (C.c_int, [_P, _P, C.c_int, _P]),
+    "ixtts_gpt_beam_begin_group": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64, _P]),
+    "ixtts_gpt_beam_park_group": (C.c_int, [_P, C.c_int, _P]),
+    "ixtts_gpt_beam_decode_groups": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(SamplerCfg), _P]),
+    "ixtts_gpt_beam_read_group": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), _P, _P, _P, _P]),
+    "ixtts_gpt_beam_force_group": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     "ixtts_gpt_read_probs": (C.c_int, [_P, C.c_int, _P, _P]),
     "ixtts_gpt_force_next": (C.c_int, [_P, C.c_int, C.c_int32, _P]),
     "ixtts_gpt_latent": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P]),

@@ -8,15 +8,18 @@
 //   indextts/gpt/model_v2.py:199-212                          _reorder_cache (index_select of every K/V)
 // `finalize` (transformers_beam_search.py:320-417) runs on the host in ixtts_gpt_beam_read.
 //
-// Beams live in sequence slots 0..NB-1 of the engine; reordering (token histories, `seen`
-// bitmaps, K/V rows of the generated positions) is done in place, element-wise: every thread
-// reads its element from all source beams before writing any destination.
+// A beam GROUP (the beams of one prompt) lives in sequence slots g*NB .. g*NB+NB-1 of the engine; reordering (token
+// histories, `seen` bitmaps, K/V rows of the generated positions) is done in place, element-wise: every thread reads its
+// element from all source beams before writing any destination.  Several groups -- the text segments of one request, or of
+// several requests (infer_v2.py:616 decodes them one after another) -- step together: every kernel below takes the group
+// from its block index and works on that group's slots and that group's scorer state only, so a group's tokens do not
+// depend on its company (tests/test_gpu_beam_groups.py).
 #include "gpt_engine.h"
 #include "gpt_kernels.h"
 
 namespace ixtts {
 
-constexpr int BEAM_MAX = 4;
+static_assert(BEAM_MAX == 4, "pick4 / the 16-entry lcp table below");
 
 constexpr int JOINT_MAX = BEAM_MAX * SAMP_MAXK;
 
@@ -36,8 +39,41 @@ struct BeamArgs {
   int* cand_i;          // [NB][SAMP_MAXK] their token ids
   int* cand_n;          // [NB] how many survive TopK + TopP
   int* lcp;             // [BEAM_MAX][BEAM_MAX] leading generated K/V rows two slots share, then [BEAM_MAX] first row each slot must take from its source
+  const unsigned long long* stream;  // [G] RNG stream of each group (0: the plain seed)
   int NB;
+  int G;                // groups stepping together; group g owns slots g*NB.., scalars at [g], per-slot arrays at [g*NB + beam]
 };
+
+// The arguments as group g sees them: per-slot arrays start at its first slot, per-group scalars at its entry.
+__device__ __forceinline__ BeamArgs beam_group_view(const BeamArgs& in, int g) {
+  BeamArgs a = in;
+  const size_t sb = (size_t)g * in.NB;
+  SamplerState& s = a.s;
+  s.logits += sb * s.V;
+  s.seen += sb * s.V;
+  s.tokens += sb * s.max_new;
+  s.gen_count += sb;
+  s.cur_len += sb;
+  s.prompt_len += sb;
+  s.finished += sb;
+  s.h += sb * s.D;
+  a.beam_scores += sb;
+  a.src += sb;
+  a.hyp_score += sb;
+  a.hyp_len += sb;
+  a.hyp_tok += sb * s.max_new;
+  a.n_hyp += g;
+  a.worst += g;
+  a.done += g;
+  a.forced += (size_t)g * BEAM_FORCED_STRIDE;
+  a.forced_flag += g;
+  a.cand_v += sb * SAMP_MAXK;
+  a.cand_i += sb * SAMP_MAXK;
+  a.cand_n += sb;
+  a.lcp += (size_t)g * BEAM_LCP_STRIDE;
+  a.stream += g;
+  return a;
+}
 
 // Phase A, one workgroup per beam: log_softmax -> penalty -> temperature -> TopK (min keep 2) -> TopP (min keep 2); the
 // survivors go to global memory sorted by score.  (As one workgroup looping over the beams, with the TopP sums on one
@@ -64,7 +100,7 @@ __global__ __launch_bounds__(1024) void beam_cand_kernel(BeamArgs a) {
     sn[i] = seen[v];
   }
   const ixtts_sampler_cfg cfg = *s.cfg;
-  const int done = *a.done;
+  const int done = a.done[b / a.NB];  // (b is the engine slot: beam b % NB of group b / NB)
   __builtin_amdgcn_sched_barrier(0);
   if (done) return;  // hypotheses complete: HF leaves the loop here; later graph replays are no-ops
   DBG_TS(1);
@@ -129,7 +165,8 @@ __global__ __launch_bounds__(1024) void beam_cand_kernel(BeamArgs a) {
 // reductions or unrolled selects over padded register arrays (16 us that way, 20 us as eight barrier-separated phases).
 // Everything whose address is known at entry is loaded up front; waves 1..15 fetch the rows they will permute (token
 // histories, `seen` flags) while wave 0 runs the scorer.
-__global__ __launch_bounds__(1024) void beam_step_kernel(BeamArgs a) {
+__global__ __launch_bounds__(1024) void beam_step_kernel(BeamArgs a_all) {
+  const BeamArgs a = beam_group_view(a_all, blockIdx.x);  // one workgroup per group
   __shared__ alignas(16) float j_key[JOINT_MAX + 4];
   __shared__ float pick_score[2 * BEAM_MAX], q_sc[2 * BEAM_MAX], nb_score[BEAM_MAX], hs_s[BEAM_MAX];
   __shared__ int pick_tok[2 * BEAM_MAX], pick_beam[2 * BEAM_MAX], q_tok[2 * BEAM_MAX], q_beam[2 * BEAM_MAX], forced_s[2 * BEAM_MAX];
@@ -150,6 +187,7 @@ __global__ __launch_bounds__(1024) void beam_step_kernel(BeamArgs a) {
   const int st_lcp = a.lcp[t & (BEAM_MAX * BEAM_MAX - 1)];
   const int st_pick = a.forced[min(t, 2 * NB - 1)];
   const float st_hs = a.hyp_score[min(t, NB - 1)];
+  const unsigned long long st_stream = *a.stream;
   // survivor (beam t / 128, rank t % 128) of this thread
   const int my_b = min(t >> 7, NB - 1), my_r = t & (SAMP_MAXK - 1);
   const float my_v = a.cand_v[my_b * SAMP_MAXK + my_r], my_bs = a.beam_scores[my_b];
@@ -196,7 +234,7 @@ __global__ __launch_bounds__(1024) void beam_step_kernel(BeamArgs a) {
   float key = -INFINITY;
   if (valid && !forced) {
     // joint multinomial(2*NB) without replacement == the 2*NB largest of score + Gumbel noise (p / Exp(1) top-k)
-    float u = uniform01(cfg.seed, (unsigned int)q, (unsigned int)kstep);
+    float u = uniform01(cfg.seed + st_stream * 0xD1B54A32D192ED03ull, (unsigned int)q, (unsigned int)kstep);
     u = fminf(fmaxf(u, 1e-7f), 1.0f - 1e-7f);
     key = score - logf(-logf(u));
     j_key[q] = key;
@@ -433,7 +471,14 @@ constexpr int REORDER_CPT = 4, REORDER_GX = 2;  // 2 x 1024 chunks = 256 rows of
 __global__ __launch_bounds__(256) void beam_reorder_kv_kernel(void* kc, void* vc, const int* src, const int* lo, const int* prompt_len,
                                                                const int* cur_len, const int* done, int NB, int H, int smax,
                                                                size_t layer_stride_bytes, size_t slot_stride_bytes, int row_bytes, int every_row) {
-  if (*done) return;
+  // grid.x = REORDER_GX workgroups per group: rebase everything on this group's first slot
+  const int grp = blockIdx.x / REORDER_GX, bx = blockIdx.x % REORDER_GX;
+  const size_t sb = (size_t)grp * NB;
+  if (done[grp]) return;
+  src += sb;
+  lo += (size_t)grp * BEAM_LCP_STRIDE;
+  prompt_len += sb;
+  cur_len += sb;
   const int p0 = prompt_len[0];
   const int rows = cur_len[0] - p0;  // generated rows already in the cache
   int sj[BEAM_MAX], lj[BEAM_MAX];
@@ -445,10 +490,10 @@ __global__ __launch_bounds__(256) void beam_reorder_kv_kernel(void* kc, void* vc
   }
   const int cpr = row_bytes / 16;
   const int total = (rows - lo_min) * cpr;  // 16-byte chunks to look at, counted back from the newest row's last
-  if ((int)(blockIdx.x * REORDER_CPT * 256) >= total) return;
+  if ((int)(bx * REORDER_CPT * 256) >= total) return;
   const int layer = blockIdx.z >> 1, is_v = blockIdx.z & 1, hh = blockIdx.y;
-  char* base0 = (char*)(is_v ? vc : kc) + layer * layer_stride_bytes + ((size_t)hh * smax + p0) * row_bytes;
-  for (int blk = blockIdx.x; blk * REORDER_CPT * 256 < total; blk += gridDim.x) {
+  char* base0 = (char*)(is_v ? vc : kc) + layer * layer_stride_bytes + sb * slot_stride_bytes + ((size_t)hh * smax + p0) * row_bytes;
+  for (int blk = bx; blk * REORDER_CPT * 256 < total; blk += REORDER_GX) {
 #pragma unroll
     for (int c = 0; c < REORDER_CPT; ++c) {
       const int back = (blk * REORDER_CPT + c) * 256 + threadIdx.x;
@@ -483,13 +528,15 @@ void launch_beam_step(ixtts_gpt* h, const SamplerState& s, hipStream_t st) {
   a.cand_i = h->beam_cand_i;
   a.cand_n = h->beam_cand_n;
   a.lcp = h->beam_lcp;
+  a.stream = h->beam_stream;
   a.NB = h->num_beams;
-  hipLaunchKernelGGL(beam_cand_kernel, dim3(h->num_beams), dim3(1024), 0, st, a);
-  hipLaunchKernelGGL(beam_step_kernel, dim3(1), dim3(1024), 0, st, a);
+  a.G = h->beam_groups;
+  hipLaunchKernelGGL(beam_cand_kernel, dim3(h->num_beams * h->beam_groups), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(beam_step_kernel, dim3(h->beam_groups), dim3(1024), 0, st, a);
   const int row_bytes = HD * (int)h->esize;
   const size_t slot_stride = (size_t)h->D * h->smax * h->esize;
   const size_t layer_stride = (size_t)h->slots * slot_stride;
-  dim3 grid(REORDER_GX, h->H, h->L * 2);
+  dim3 grid(REORDER_GX * h->beam_groups, h->H, h->L * 2);
   hipLaunchKernelGGL(beam_reorder_kv_kernel, grid, dim3(256), 0, st, h->kc, h->vc, (const int*)h->beam_src, (const int*)(h->beam_lcp + BEAM_MAX * BEAM_MAX), (const int*)h->prompt_len,
                      (const int*)h->cur_len, (const int*)h->beam_done, h->num_beams, h->H, h->smax, layer_stride, slot_stride, row_bytes,
                      h->beam_every_row ? 1 : 0);

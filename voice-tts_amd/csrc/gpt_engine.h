@@ -11,6 +11,12 @@ namespace ixtts {
 constexpr int MAXB = 16;       // decode slots stepped together: 1..4 on the register GEMVs, 5..16 ("wide" engines) on the matrix cores (gpt_wide.h)
 constexpr int MAXB_REG = 4;
 constexpr int STEPS_PER_GRAPH = 8;
+// beam-sample (gpt_beam.hip): beams per group, groups stepping together (group g owns slots g*NB .. g*NB+NB-1), and the strides
+// of the per-group tables
+constexpr int BEAM_MAX = 4;
+constexpr int MAXG = MAXB / 2;
+constexpr int BEAM_LCP_STRIDE = BEAM_MAX * BEAM_MAX + BEAM_MAX;  // [BEAM_MAX][BEAM_MAX] shared leading rows, then [BEAM_MAX] first row to copy
+constexpr int BEAM_FORCED_STRIDE = 2 * BEAM_MAX;
 
 enum TKind { T_VEC = 0, T_MAT_T = 1, T_MAT_N = 2, T_EMB = 3 };
 
@@ -94,8 +100,13 @@ struct ixtts_gpt {
   int attn_bucket = ixtts::NBKT;  // bucket the graph being captured is built for
   int host_prompt_len[ixtts::MAXB + 2];
   int host_gen_est[ixtts::MAXB + 2];
-  // beam-sample state (gpt_beam.hip): beams occupy slots 0..num_beams-1
+  // beam-sample state (gpt_beam.hip): group g's beams occupy slots g*num_beams .. g*num_beams+num_beams-1; per-slot arrays
+  // are indexed by the slot, per-group scalars by the group
   int num_beams = 0;
+  int beam_groups = 1;                            // groups the launch being issued / captured steps
+  bool group_live[ixtts::MAXG] = {};              // begun and not parked: its context counts for buckets and overflow checks
+  bool group_begun[ixtts::MAXG] = {};             // device state initialised at least once
+  unsigned long long* beam_stream = nullptr;      // [MAXG] RNG stream per group
   float *beam_scores = nullptr, *hyp_score = nullptr, *hyp_worst = nullptr;
   int *beam_src = nullptr, *hyp_len = nullptr, *n_hyp = nullptr, *beam_done = nullptr, *beam_forced_flag = nullptr;
   int32_t *hyp_tok = nullptr, *beam_forced = nullptr;
@@ -103,7 +114,7 @@ struct ixtts_gpt {
   int *beam_cand_i = nullptr, *beam_cand_n = nullptr;
   bool beam_every_row = false;  // IXTTS_BEAM_REORDER=full: move every generated row at each reorder (A/B test of the shared-prefix bookkeeping)
   int* beam_lcp = nullptr;  // [MAXB*MAXB] leading generated K/V rows known identical between two beams' slots, then [MAXB] first row to copy
-  hipGraphExec_t beam_exec[ixtts::NBKT + 1] = {}, beam_multi_exec[ixtts::NBKT + 1] = {};
+  hipGraphExec_t beam_exec[ixtts::MAXG + 1][ixtts::NBKT + 1] = {}, beam_multi_exec[ixtts::MAXG + 1][ixtts::NBKT + 1] = {};  // per (groups, bucket)
   int beam_exec_nb = 0;
   // batched-rows workspace (prefill / latent): [max_seq][D] x4 + [max_seq][4D]
   float *rx = nullptr, *rxn = nullptr, *rq = nullptr, *ratt = nullptr, *rff = nullptr;

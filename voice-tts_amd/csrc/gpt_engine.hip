@@ -441,18 +441,19 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   ok &= hipMalloc(&h->d_samp, sizeof(ixtts_sampler_cfg)) == hipSuccess;
   ok &= hipMalloc(&h->beam_scores, MAXB * 4) == hipSuccess;
   ok &= hipMalloc(&h->hyp_score, MAXB * 4) == hipSuccess;
-  ok &= hipMalloc(&h->hyp_worst, 4) == hipSuccess;
+  ok &= hipMalloc(&h->hyp_worst, MAXG * 4) == hipSuccess;
   ok &= hipMalloc(&h->beam_src, MAXB * 4) == hipSuccess;
   ok &= hipMalloc(&h->hyp_len, MAXB * 4) == hipSuccess;
-  ok &= hipMalloc(&h->n_hyp, 4) == hipSuccess;
-  ok &= hipMalloc(&h->beam_done, 4) == hipSuccess;
-  ok &= hipMalloc(&h->beam_forced_flag, 4) == hipSuccess;
-  ok &= hipMalloc(&h->beam_forced, 2 * MAXB * 4) == hipSuccess;
+  ok &= hipMalloc(&h->n_hyp, MAXG * 4) == hipSuccess;
+  ok &= hipMalloc(&h->beam_done, MAXG * 4) == hipSuccess;
+  ok &= hipMalloc(&h->beam_forced_flag, MAXG * 4) == hipSuccess;
+  ok &= hipMalloc(&h->beam_forced, (size_t)MAXG * BEAM_FORCED_STRIDE * 4) == hipSuccess;
+  ok &= hipMalloc(&h->beam_stream, MAXG * 8) == hipSuccess;
   ok &= hipMalloc(&h->hyp_tok, (size_t)MAXB * h->smax * 4) == hipSuccess;
   ok &= hipMalloc(&h->beam_cand_v, (size_t)MAXB * SAMP_MAXK * 4) == hipSuccess;
   ok &= hipMalloc(&h->beam_cand_i, (size_t)MAXB * SAMP_MAXK * 4) == hipSuccess;
   ok &= hipMalloc(&h->beam_cand_n, (size_t)MAXB * 4) == hipSuccess;
-  ok &= hipMalloc(&h->beam_lcp, (size_t)(MAXB * MAXB + MAXB) * 4) == hipSuccess;
+  ok &= hipMalloc(&h->beam_lcp, (size_t)MAXG * BEAM_LCP_STRIDE * 4) == hipSuccess;
   ok &= hipMalloc(&h->probs, (size_t)S * V * 4) == hipSuccess;
   h->scratch_floats = (size_t)FF * D;
   ok &= hipMalloc(&h->scratch, h->scratch_floats * 4) == hipSuccess;
@@ -465,6 +466,16 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   hipMemset(h->forced, 0xff, S * 4);
   hipMemset(h->seen, 0, (size_t)S * V);
   hipMemset(h->logits, 0, (size_t)S * V * 4);
+  {  // every beam group starts parked (done): a group below a stepping one that was never begun is a no-op in the beam kernels
+    int ones[MAXG];
+    for (int g = 0; g < MAXG; ++g) ones[g] = 1;
+    hipMemcpy(h->beam_done, ones, sizeof(ones), hipMemcpyHostToDevice);
+    hipMemset(h->beam_forced_flag, 0, MAXG * 4);
+    hipMemset(h->beam_stream, 0, MAXG * 8);
+    hipMemset(h->n_hyp, 0, MAXG * 4);
+    hipMemset(h->beam_lcp, 0, (size_t)MAXG * BEAM_LCP_STRIDE * 4);
+    hipMemset(h->beam_src, 0, MAXB * 4);
+  }
   if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
   if (const char* e = getenv("IXTTS_ATTN")) h->attn_split = strcmp(e, "legacy") != 0;
   h->wide = c->max_batch > MAXB_REG;
@@ -740,114 +751,174 @@ extern "C" int ixtts_gpt_decode(ixtts_gpt* h, int n_active, int n_steps, const i
 }
 
 // ------------------------------------------------------------------------------------ beam-sample
-extern "C" int ixtts_gpt_beam_begin(ixtts_gpt* h, int num_beams, void* stream) {
-  NEED_READY(h, "gpt_beam_begin");
-  IX_ARG(num_beams >= 2 && num_beams <= h->cfg.max_batch && num_beams <= MAXB_REG, "gpt_beam_begin: num_beams %d needs max_batch >= it (<= %d)", num_beams, MAXB_REG);
-  IX_ARG(h->host_prompt_len[0] > 0, "gpt_beam_begin: slot 0 has no prefilled prompt");
-  hipStream_t st = (hipStream_t)stream;
+// Group g = the beams of ONE prompt, in slots g*NB .. g*NB+NB-1.  Engines of up to 4 slots hold one group (register GEMVs);
+// wide engines (5..16 slots, bf16) hold floor(max_batch / NB) groups that step together: the text segments of a request, or
+// of several requests, each with its own scorer state (the reference decodes them one after another, infer_v2.py:616).
+static int beam_begin_impl(ixtts_gpt* h, int g, int num_beams, unsigned long long stream_id, hipStream_t st) {
+  IX_ARG(num_beams >= 2 && num_beams <= BEAM_MAX, "gpt_beam_begin: num_beams %d (2..%d)", num_beams, BEAM_MAX);
+  IX_ARG(g >= 0 && g < MAXG && (g + 1) * num_beams <= h->cfg.max_batch, "gpt_beam_begin: group %d of %d beams needs max_batch >= %d (have %d)", g, num_beams,
+         (g + 1) * num_beams, h->cfg.max_batch);
+  for (int o = 0; o < MAXG; ++o)
+    if (o != g && h->group_live[o]) IX_ARG(h->num_beams == num_beams, "gpt_beam_begin: live groups hold %d beams each, group %d asks for %d", h->num_beams, g, num_beams);
+  const int sb = g * num_beams;
+  IX_ARG(h->host_prompt_len[sb] > 0, "gpt_beam_begin: slot %d (first of group %d) has no prefilled prompt", sb, g);
   const int D = h->D, V = h->V;
   const size_t slot_bytes = (size_t)D * h->smax * h->esize;
   const size_t layer_bytes = (size_t)h->slots * slot_bytes;
   // input_ids.repeat_interleave(num_beams): every beam starts as a copy of the prefilled sequence
-  for (int b = 1; b < num_beams; ++b) {
+  for (int b = sb + 1; b < sb + num_beams; ++b) {
     for (int l = 0; l < h->L; ++l) {
-      IX_HIP(hipMemcpyAsync((char*)h->kc + l * layer_bytes + b * slot_bytes, (char*)h->kc + l * layer_bytes, slot_bytes, hipMemcpyDeviceToDevice, st));
-      IX_HIP(hipMemcpyAsync((char*)h->vc + l * layer_bytes + b * slot_bytes, (char*)h->vc + l * layer_bytes, slot_bytes, hipMemcpyDeviceToDevice, st));
+      IX_HIP(hipMemcpyAsync((char*)h->kc + l * layer_bytes + b * slot_bytes, (char*)h->kc + l * layer_bytes + sb * slot_bytes, slot_bytes, hipMemcpyDeviceToDevice, st));
+      IX_HIP(hipMemcpyAsync((char*)h->vc + l * layer_bytes + b * slot_bytes, (char*)h->vc + l * layer_bytes + sb * slot_bytes, slot_bytes, hipMemcpyDeviceToDevice, st));
     }
-    IX_HIP(hipMemcpyAsync(h->logits + (size_t)b * V, h->logits, (size_t)V * 4, hipMemcpyDeviceToDevice, st));
-    IX_HIP(hipMemcpyAsync(h->seen + (size_t)b * V, h->seen, V, hipMemcpyDeviceToDevice, st));
-    IX_HIP(hipMemcpyAsync(h->prompt_len + b, h->prompt_len, 4, hipMemcpyDeviceToDevice, st));
-    IX_HIP(hipMemcpyAsync(h->valid_from + b, h->valid_from, 4, hipMemcpyDeviceToDevice, st));
-    IX_HIP(hipMemcpyAsync(h->gen_count + b, h->gen_count, 4, hipMemcpyDeviceToDevice, st));
-    IX_HIP(hipMemcpyAsync(h->finished + b, h->finished, 4, hipMemcpyDeviceToDevice, st));
-    h->host_prompt_len[b] = h->host_prompt_len[0];
-    h->host_gen_est[b] = h->host_gen_est[0];
+    IX_HIP(hipMemcpyAsync(h->logits + (size_t)b * V, h->logits + (size_t)sb * V, (size_t)V * 4, hipMemcpyDeviceToDevice, st));
+    IX_HIP(hipMemcpyAsync(h->seen + (size_t)b * V, h->seen + (size_t)sb * V, V, hipMemcpyDeviceToDevice, st));
+    IX_HIP(hipMemcpyAsync(h->prompt_len + b, h->prompt_len + sb, 4, hipMemcpyDeviceToDevice, st));
+    IX_HIP(hipMemcpyAsync(h->valid_from + b, h->valid_from + sb, 4, hipMemcpyDeviceToDevice, st));
+    IX_HIP(hipMemcpyAsync(h->gen_count + b, h->gen_count + sb, 4, hipMemcpyDeviceToDevice, st));
+    IX_HIP(hipMemcpyAsync(h->finished + b, h->finished + sb, 4, hipMemcpyDeviceToDevice, st));
+    h->host_prompt_len[b] = h->host_prompt_len[sb];
+    h->host_gen_est[b] = h->host_gen_est[sb];
   }
   // beam_scores = [0, -1e9, ...] so only beam 0's tokens can be drawn at the first step (generation_utils.py:3406-3410)
-  float bs[MAXB];
-  for (int b = 0; b < MAXB; ++b) bs[b] = b == 0 ? 0.f : -1e9f;
-  IX_HIP(hipMemcpyAsync(h->beam_scores, bs, num_beams * 4, hipMemcpyHostToDevice, st));
+  float bs[BEAM_MAX];
+  for (int b = 0; b < BEAM_MAX; ++b) bs[b] = b == 0 ? 0.f : -1e9f;
+  IX_HIP(hipMemcpyAsync(h->beam_scores + sb, bs, num_beams * 4, hipMemcpyHostToDevice, st));
   const float worst = 1e9f;
-  IX_HIP(hipMemcpyAsync(h->hyp_worst, &worst, 4, hipMemcpyHostToDevice, st));
-  IX_HIP(hipMemsetAsync(h->n_hyp, 0, 4, st));
-  IX_HIP(hipMemsetAsync(h->beam_done, 0, 4, st));
-  IX_HIP(hipMemsetAsync(h->beam_forced_flag, 0, 4, st));
-  IX_HIP(hipMemsetAsync(h->beam_lcp, 0, (size_t)(MAXB * MAXB + MAXB) * 4, st));  // no generated rows yet
-  IX_HIP(hipStreamSynchronize(st));  // bs / worst are stack variables
+  IX_HIP(hipMemcpyAsync(h->hyp_worst + g, &worst, 4, hipMemcpyHostToDevice, st));
+  IX_HIP(hipMemcpyAsync(h->beam_stream + g, &stream_id, 8, hipMemcpyHostToDevice, st));
+  IX_HIP(hipMemsetAsync(h->n_hyp + g, 0, 4, st));
+  IX_HIP(hipMemsetAsync(h->beam_done + g, 0, 4, st));
+  IX_HIP(hipMemsetAsync(h->beam_forced_flag + g, 0, 4, st));
+  IX_HIP(hipMemsetAsync(h->beam_lcp + (size_t)g * BEAM_LCP_STRIDE, 0, (size_t)BEAM_LCP_STRIDE * 4, st));  // no generated rows yet
+  IX_HIP(hipStreamSynchronize(st));  // bs / worst / stream_id are stack variables
   h->num_beams = num_beams;
+  h->group_live[g] = h->group_begun[g] = true;
+  return IXTTS_OK;
+}
+
+extern "C" int ixtts_gpt_beam_begin(ixtts_gpt* h, int num_beams, void* stream) {
+  NEED_READY(h, "gpt_beam_begin");
+  return beam_begin_impl(h, 0, num_beams, 0ull, (hipStream_t)stream);
+}
+
+extern "C" int ixtts_gpt_beam_begin_group(ixtts_gpt* h, int group, int num_beams, uint64_t rng_stream, void* stream) {
+  NEED_READY(h, "gpt_beam_begin_group");
+  return beam_begin_impl(h, group, num_beams, (unsigned long long)rng_stream, (hipStream_t)stream);
+}
+
+// A group that has no prompt to work on while others step: its kernels are no-ops (done flag), its slots keep their last
+// K/V position, and its context no longer counts for the overflow check.
+extern "C" int ixtts_gpt_beam_park_group(ixtts_gpt* h, int group, void* stream) {
+  NEED_READY(h, "gpt_beam_park_group");
+  IX_ARG(group >= 0 && group < MAXG, "gpt_beam_park_group: group %d", group);
+  hipStream_t st = (hipStream_t)stream;
+  static const int one = 1;
+  IX_HIP(hipMemcpyAsync(h->beam_done + group, &one, 4, hipMemcpyHostToDevice, st));
+  h->group_live[group] = false;
+  return IXTTS_OK;
+}
+
+static int beam_force_impl(ixtts_gpt* h, int g, const int32_t* picks, int n, hipStream_t st) {
+  IX_ARG(h->num_beams >= 2 && g >= 0 && g < MAXG && h->group_live[g] && picks && n == 2 * h->num_beams, "gpt_beam_force: need 2*num_beams picks for a begun group");
+  const int one = 1;
+  IX_HIP(hipMemcpyAsync(h->beam_forced + (size_t)g * BEAM_FORCED_STRIDE, picks, n * 4, hipMemcpyHostToDevice, st));
+  IX_HIP(hipMemcpyAsync(h->beam_forced_flag + g, &one, 4, hipMemcpyHostToDevice, st));
+  IX_HIP(hipStreamSynchronize(st));
   return IXTTS_OK;
 }
 
 extern "C" int ixtts_gpt_beam_force(ixtts_gpt* h, const int32_t* picks, int n, void* stream) {
   NEED_READY(h, "gpt_beam_force");
-  IX_ARG(h->num_beams >= 2 && picks && n == 2 * h->num_beams, "gpt_beam_force: need 2*num_beams picks after beam_begin");
-  hipStream_t st = (hipStream_t)stream;
-  const int one = 1;
-  IX_HIP(hipMemcpyAsync(h->beam_forced, picks, n * 4, hipMemcpyHostToDevice, st));
-  IX_HIP(hipMemcpyAsync(h->beam_forced_flag, &one, 4, hipMemcpyHostToDevice, st));
-  IX_HIP(hipStreamSynchronize(st));
-  return IXTTS_OK;
+  return beam_force_impl(h, 0, picks, n, (hipStream_t)stream);
 }
 
-extern "C" int ixtts_gpt_beam_decode(ixtts_gpt* h, int n_steps, const ixtts_sampler_cfg* sc, void* stream) {
-  NEED_READY(h, "gpt_beam_decode");
+extern "C" int ixtts_gpt_beam_force_group(ixtts_gpt* h, int group, const int32_t* picks, int n, void* stream) {
+  NEED_READY(h, "gpt_beam_force_group");
+  return beam_force_impl(h, group, picks, n, (hipStream_t)stream);
+}
+
+static int beam_decode_impl(ixtts_gpt* h, int n_groups, int n_steps, const ixtts_sampler_cfg* sc, hipStream_t st) {
   IX_ARG(sc && n_steps >= 0, "gpt_beam_decode: bad argument");
   IX_ARG(h->num_beams >= 2, "gpt_beam_decode: call gpt_beam_begin first");
   IX_ARG(sc->top_k >= 1 && sc->top_k <= SAMP_MAXK && sc->temperature > 0.f && sc->top_p > 0.f, "gpt_beam_decode: 1 <= top_k <= %d, positive temperature/top_p", SAMP_MAXK);
   IX_ARG(h->V <= 1024 * SAMP_PT, "gpt_beam_decode: vocabulary %d exceeds the sampler tile", h->V);
   const int nb = h->num_beams;
-  IX_ARG(h->host_prompt_len[0] + h->host_gen_est[0] + n_steps < h->smax, "gpt_beam_decode: would overflow max_seq %d", h->smax);
-  hipStream_t st = (hipStream_t)stream;
+  IX_ARG(n_groups >= 1 && n_groups <= MAXG && n_groups * nb <= h->cfg.max_batch, "gpt_beam_decode: %d groups of %d beams exceed max_batch %d", n_groups, nb, h->cfg.max_batch);
+  IX_ARG(n_groups == 1 || h->wide, "gpt_beam_decode: several groups step together on the wide engines only (max_batch > %d, bf16)", MAXB_REG);
+  int ctx0 = 0, live = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    if (!h->group_live[g]) continue;  // parked (or never begun: created parked)
+    ++live;
+    const int c = h->host_prompt_len[g * nb] + h->host_gen_est[g * nb];
+    IX_ARG(c + n_steps < h->smax, "gpt_beam_decode: group %d would overflow max_seq %d", g, h->smax);
+    ctx0 = std::max(ctx0, c);
+  }
+  IX_ARG(live > 0, "gpt_beam_decode: none of the %d groups is live (gpt_beam_begin_group first)", n_groups);
   if (h->beam_exec_nb != nb) {
-    for (int k = 0; k <= NBKT; ++k) {
-      if (h->beam_exec[k]) hipGraphExecDestroy(h->beam_exec[k]);
-      if (h->beam_multi_exec[k]) hipGraphExecDestroy(h->beam_multi_exec[k]);
-      h->beam_exec[k] = h->beam_multi_exec[k] = nullptr;
-    }
+    for (int g = 0; g <= MAXG; ++g)
+      for (int k = 0; k <= NBKT; ++k) {
+        if (h->beam_exec[g][k]) hipGraphExecDestroy(h->beam_exec[g][k]);
+        if (h->beam_multi_exec[g][k]) hipGraphExecDestroy(h->beam_multi_exec[g][k]);
+        h->beam_exec[g][k] = h->beam_multi_exec[g][k] = nullptr;
+      }
     h->beam_exec_nb = nb;
   }
   h->samp_host = *sc;
   IX_HIP(hipMemcpyAsync(h->d_samp, &h->samp_host, sizeof(ixtts_sampler_cfg), hipMemcpyHostToDevice, st));
-  const int ctx0 = h->host_prompt_len[0] + h->host_gen_est[0];
+  h->beam_groups = n_groups;
   for (int done = 0; done < n_steps;) {
     const int reps = n_steps - done >= STEPS_PER_GRAPH ? STEPS_PER_GRAPH : 1;
     const int bkt = pick_bucket(h, ctx0 + done + reps + 1);
-    hipGraphExec_t* slot = reps > 1 ? &h->beam_multi_exec[bkt] : &h->beam_exec[bkt];
-    if (!*slot) IX_TRY(build_step_graph(h, nb, reps, bkt, slot, true));
+    hipGraphExec_t* slot = reps > 1 ? &h->beam_multi_exec[n_groups][bkt] : &h->beam_exec[n_groups][bkt];
+    if (!*slot) IX_TRY(build_step_graph(h, n_groups * nb, reps, bkt, slot, true));
     IX_HIP(hipGraphLaunch(*slot, st));
     done += reps;
   }
-  for (int b = 0; b < nb; ++b) h->host_gen_est[b] += n_steps;
+  for (int g = 0; g < n_groups; ++g)
+    if (h->group_live[g])
+      for (int b = g * nb; b < (g + 1) * nb; ++b) h->host_gen_est[b] += n_steps;
   return IXTTS_OK;
 }
 
+extern "C" int ixtts_gpt_beam_decode(ixtts_gpt* h, int n_steps, const ixtts_sampler_cfg* sc, void* stream) {
+  NEED_READY(h, "gpt_beam_decode");
+  return beam_decode_impl(h, 1, n_steps, sc, (hipStream_t)stream);
+}
+
+extern "C" int ixtts_gpt_beam_decode_groups(ixtts_gpt* h, int n_groups, int n_steps, const ixtts_sampler_cfg* sc, void* stream) {
+  NEED_READY(h, "gpt_beam_decode_groups");
+  return beam_decode_impl(h, n_groups, n_steps, sc, (hipStream_t)stream);
+}
+
 // BeamSearchScorer.finalize (transformers_beam_search.py:320-417), num_return_sequences = 1, on the host.
-extern "C" int ixtts_gpt_beam_read(ixtts_gpt* h, int max_new, int32_t* ids, int cap, int* n_ids, int* done, float* score,
-                                   float* beam_scores_out, int32_t* last_tokens_out, int32_t* src_out, void* stream) {
-  NEED_READY(h, "gpt_beam_read");
+static int beam_read_impl(ixtts_gpt* h, int g, int max_new, int32_t* ids, int cap, int* n_ids, int* done, float* score,
+                          float* beam_scores_out, int32_t* last_tokens_out, int32_t* src_out, hipStream_t st) {
   IX_ARG(h->num_beams >= 2 && ids && n_ids && done && cap >= 0 && max_new >= 0, "gpt_beam_read: bad argument");
-  hipStream_t st = (hipStream_t)stream;
+  IX_ARG(g >= 0 && g < MAXG && h->group_begun[g], "gpt_beam_read: group %d was never begun", g);
   IX_HIP(hipStreamSynchronize(st));
   const int nb = h->num_beams;
+  const int sb = g * nb;
   int gc = 0, dn = 0, nh = 0;
   float bs[MAXB], hs[MAXB];
   int hl[MAXB], src[MAXB];
-  IX_HIP(hipMemcpy(&gc, h->gen_count, 4, hipMemcpyDeviceToHost));
-  IX_HIP(hipMemcpy(&dn, h->beam_done, 4, hipMemcpyDeviceToHost));
-  IX_HIP(hipMemcpy(&nh, h->n_hyp, 4, hipMemcpyDeviceToHost));
-  IX_HIP(hipMemcpy(bs, h->beam_scores, nb * 4, hipMemcpyDeviceToHost));
-  IX_HIP(hipMemcpy(hs, h->hyp_score, nb * 4, hipMemcpyDeviceToHost));
-  IX_HIP(hipMemcpy(hl, h->hyp_len, nb * 4, hipMemcpyDeviceToHost));
-  IX_HIP(hipMemcpy(src, h->beam_src, nb * 4, hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(&gc, h->gen_count + sb, 4, hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(&dn, h->beam_done + g, 4, hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(&nh, h->n_hyp + g, 4, hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(bs, h->beam_scores + sb, nb * 4, hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(hs, h->hyp_score + sb, nb * 4, hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(hl, h->hyp_len + sb, nb * 4, hipMemcpyDeviceToHost));
+  IX_HIP(hipMemcpy(src, h->beam_src + sb, nb * 4, hipMemcpyDeviceToHost));
   gc = std::min(gc, h->smax);
+  nh = std::max(0, std::min(nh, nb));
   std::vector<std::vector<int32_t>> open(nb), hyp(nh);
   for (int b = 0; b < nb; ++b) {
     open[b].resize(gc);
-    if (gc) IX_HIP(hipMemcpy(open[b].data(), h->tokens + (size_t)b * h->smax, (size_t)gc * 4, hipMemcpyDeviceToHost));
+    if (gc) IX_HIP(hipMemcpy(open[b].data(), h->tokens + (size_t)(sb + b) * h->smax, (size_t)gc * 4, hipMemcpyDeviceToHost));
   }
   for (int i = 0; i < nh; ++i) {
     hyp[i].resize(hl[i]);
-    if (hl[i]) IX_HIP(hipMemcpy(hyp[i].data(), h->hyp_tok + (size_t)i * h->smax, (size_t)hl[i] * 4, hipMemcpyDeviceToHost));
+    if (hl[i]) IX_HIP(hipMemcpy(hyp[i].data(), h->hyp_tok + (size_t)(sb + i) * h->smax, (size_t)hl[i] * 4, hipMemcpyDeviceToHost));
   }
   if (beam_scores_out) memcpy(beam_scores_out, bs, nb * 4);
   if (src_out) memcpy(src_out, src, nb * 4);
@@ -891,6 +962,18 @@ extern "C" int ixtts_gpt_beam_read(ixtts_gpt* h, int max_new, int32_t* ids, int 
   *done = dn;
   if (score) *score = beams[bi].first;
   return IXTTS_OK;
+}
+
+extern "C" int ixtts_gpt_beam_read(ixtts_gpt* h, int max_new, int32_t* ids, int cap, int* n_ids, int* done, float* score,
+                                   float* beam_scores_out, int32_t* last_tokens_out, int32_t* src_out, void* stream) {
+  NEED_READY(h, "gpt_beam_read");
+  return beam_read_impl(h, 0, max_new, ids, cap, n_ids, done, score, beam_scores_out, last_tokens_out, src_out, (hipStream_t)stream);
+}
+
+extern "C" int ixtts_gpt_beam_read_group(ixtts_gpt* h, int group, int max_new, int32_t* ids, int cap, int* n_ids, int* done, float* score,
+                                         float* beam_scores_out, int32_t* last_tokens_out, int32_t* src_out, void* stream) {
+  NEED_READY(h, "gpt_beam_read_group");
+  return beam_read_impl(h, group, max_new, ids, cap, n_ids, done, score, beam_scores_out, last_tokens_out, src_out, (hipStream_t)stream);
 }
 
 // The fused MLP kernel never waits forever for its XCD's workgroups: after ~13 ms it leaves a mark and goes on with what it
@@ -1019,13 +1102,15 @@ extern "C" int ixtts_gpt_destroy(ixtts_gpt* h) {
       if (h->step_exec[b][k]) hipGraphExecDestroy(h->step_exec[b][k]);
       if (h->multi_exec[b][k]) hipGraphExecDestroy(h->multi_exec[b][k]);
     }
-    if (h->beam_exec[k]) hipGraphExecDestroy(h->beam_exec[k]);
-    if (h->beam_multi_exec[k]) hipGraphExecDestroy(h->beam_multi_exec[k]);
+    for (int g = 0; g <= MAXG; ++g) {
+      if (h->beam_exec[g][k]) hipGraphExecDestroy(h->beam_exec[g][k]);
+      if (h->beam_multi_exec[g][k]) hipGraphExecDestroy(h->beam_multi_exec[g][k]);
+    }
   }
   if (h->cap_stream) hipStreamDestroy(h->cap_stream);
   void* ptrs[] = {h->arena, h->stage, h->kc, h->vc, h->h, h->q, h->ff, h->att, h->part, h->logits, h->rowbuf, h->cur_len, h->gen_count,
                   h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->probs, h->scratch, h->beam_scores, h->hyp_score, h->hyp_worst, h->beam_src, h->hyp_len,
-                  h->n_hyp, h->beam_done, h->beam_forced_flag, h->beam_forced, h->hyp_tok, h->beam_cand_v, h->beam_cand_i, h->beam_cand_n, h->beam_lcp,
+                  h->n_hyp, h->beam_done, h->beam_forced_flag, h->beam_forced, h->hyp_tok, h->beam_cand_v, h->beam_cand_i, h->beam_cand_n, h->beam_lcp, h->beam_stream,
                   h->rx, h->rxn, h->rq, h->ratt, h->rff, h->h2, h->wprx, h->mlp_part, h->mlp_ctr};
   for (void* p : ptrs)
     if (p) hipFree(p);

@@ -117,33 +117,38 @@ class GptEngine:
             _lib.check(_lib.lib().ixtts_gpt_force_next(self._h, slot, int(token), self._stream()), "ixtts_gpt_force_next")
 
     # ------------------------------------------------------------------ beam-sample
-    def beam_begin(self, num_beams):
+    # Group g = the beams of one prompt (prefilled into slot g * num_beams); groups step together on a wide engine.
+    def beam_begin(self, num_beams, group=0, rng_stream=0):
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().ixtts_gpt_beam_begin(self._h, int(num_beams), self._stream()), "ixtts_gpt_beam_begin")
+            _lib.check(_lib.lib().ixtts_gpt_beam_begin_group(self._h, int(group), int(num_beams), int(rng_stream), self._stream()), "ixtts_gpt_beam_begin_group")
         self._nb = int(num_beams)
 
+    def beam_park(self, group):
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ixtts_gpt_beam_park_group(self._h, int(group), self._stream()), "ixtts_gpt_beam_park_group")
+
     def beam_decode(self, n_steps, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=False, seed=0, typical_mass=0.0,
-                    length_penalty=0.0):
+                    length_penalty=0.0, groups=1):
         sc = _lib.SamplerCfg(repetition_penalty, temperature, top_k, top_p, 1, int(suppress_stop), seed, float(typical_mass), float(length_penalty))
         self._lp = float(length_penalty)
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().ixtts_gpt_beam_decode(self._h, n_steps, C.byref(sc), self._stream()), "ixtts_gpt_beam_decode")
+            _lib.check(_lib.lib().ixtts_gpt_beam_decode_groups(self._h, int(groups), n_steps, C.byref(sc), self._stream()), "ixtts_gpt_beam_decode_groups")
 
-    def beam_force(self, picks):
+    def beam_force(self, picks, group=0):
         a = np.ascontiguousarray(np.asarray(picks, dtype=np.int32))
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().ixtts_gpt_beam_force(self._h, a.ctypes.data, a.size, self._stream()), "ixtts_gpt_beam_force")
+            _lib.check(_lib.lib().ixtts_gpt_beam_force_group(self._h, int(group), a.ctypes.data, a.size, self._stream()), "ixtts_gpt_beam_force_group")
 
-    def beam_read(self, max_new):
+    def beam_read(self, max_new, group=0):
         ids = np.zeros(self.max_seq + 1, dtype=np.int32)
         n, done, score = C.c_int(), C.c_int(), C.c_float()
         bs = np.zeros(self._nb, np.float32)
         lt = np.zeros(self._nb, np.int32)
         src = np.zeros(self._nb, np.int32)
         with torch.cuda.device(self.device):
-            rc = _lib.lib().ixtts_gpt_beam_read(self._h, int(max_new), ids.ctypes.data, ids.size, C.byref(n), C.byref(done), C.byref(score),
-                                                bs.ctypes.data, lt.ctypes.data, src.ctypes.data, self._stream())
-        _lib.check(rc, "ixtts_gpt_beam_read")
+            rc = _lib.lib().ixtts_gpt_beam_read_group(self._h, int(group), int(max_new), ids.ctypes.data, ids.size, C.byref(n), C.byref(done), C.byref(score),
+                                                      bs.ctypes.data, lt.ctypes.data, src.ctypes.data, self._stream())
+        _lib.check(rc, "ixtts_gpt_beam_read_group")
         return ids[: n.value].copy(), bool(done.value), float(score.value), bs, lt, src
 
     def latent(self, prefix, codes):

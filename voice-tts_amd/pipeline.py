@@ -139,6 +139,22 @@ class HotPath:
                                           repetition_penalty=repetition_penalty)
         return out
 
+    def generate_beams_many(self, segments, num_beams=3, fixed_length=False, sync_every=64, repetition_penalty=10.0, temperature=0.8,
+                            top_k=30, top_p=0.8, seed=0, length_penalty=0.0, typical_mass=0.0):
+        """The served default (`num_beams=3` beam-sample, infer_v2.py:598-606) for any number of segments: each segment is a
+        beam group of `num_beams` slots, the engine's groups step together (a wide engine holds floor(max_batch / num_beams);
+        up to 4 slots: one group, the segments in turn as the reference runs them).  segments: list of (embeds [P-1,D],
+        n_left_pad, max_new).  Returns the best hypothesis per segment, in submission order."""
+        from .scheduler import BeamGroupScheduler, Segment
+
+        out = [None] * len(segments)
+        sched = BeamGroupScheduler(self.gpt, num_beams, sync_every=sync_every)
+        segs = [Segment(0, i, e, p, n) for i, (e, p, n) in enumerate(segments)]
+        self.last_sched_stats = sched.run(segs, lambda seg, ids, score: out.__setitem__(seg.index, ids), fixed_length=fixed_length,
+                                          repetition_penalty=repetition_penalty, temperature=temperature, top_k=top_k, top_p=top_p, seed=seed,
+                                          length_penalty=length_penalty, typical_mass=typical_mass)
+        return out
+
     # ------------------------------------------------------------------ G9
     def latent(self, conds_latent, text_ids, codes):
         prefix = self.latent_prefix(conds_latent, text_ids)

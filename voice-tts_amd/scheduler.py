@@ -15,10 +15,11 @@ import numpy as np
 class Segment:
     """One text segment of one request, ready for the decode engine."""
 
-    __slots__ = ("request", "index", "embeds", "n_left_pad", "max_new", "payload")
+    __slots__ = ("request", "index", "embeds", "n_left_pad", "max_new", "payload", "stream")
 
-    def __init__(self, request, index, embeds, n_left_pad, max_new, payload=None):
+    def __init__(self, request, index, embeds, n_left_pad, max_new, payload=None, stream=None):
         self.request, self.index, self.embeds, self.n_left_pad, self.max_new, self.payload = request, index, embeds, n_left_pad, max_new, payload
+        self.stream = stream  # beam groups: the random stream this segment draws from (None: its position in the submission order)
 
 
 def live_stub(engine, like):
@@ -83,4 +84,64 @@ class DecodeScheduler:
                             ids = ids[: hit[0] + 1]
                     on_done(seg, ids)
                     slots[b] = None
+        return self.stats
+
+
+class BeamGroupScheduler:
+    """The same idea for the served default (`num_beams=3` beam-sample, infer_v2.py:598-606): a text segment needs `num_beams`
+    slots -- a beam GROUP -- and the reference decodes the segments of a request one after another (infer_v2.py:616).  Here the
+    engine's groups (floor(max_batch / num_beams); group g = slots g*num_beams ..) are kept busy with queued segments: prefill
+    into a free group's first slot, `beam_begin` it, step all groups together, read a group when it has finished (scorer done
+    or max_new reached), refill or park it.  A segment draws from the random stream `segment.stream` (default: its position
+    in the submission order), so its tokens do not depend on the group it lands in or on its company
+    (tests/test_gpu_beam_groups.py holds that bit for bit against one-group-at-a-time decoding).
+
+    engine: `GptEngine`-like with prefill(slot, embeds, pad), beam_begin(num_beams, group=, rng_stream=), beam_park(group),
+    beam_decode(n_steps, groups=, **sampler), beam_read(max_new, group=) -> (ids, done, score, ...).
+    """
+
+    def __init__(self, engine, num_beams, max_groups=None, sync_every=64):
+        self.engine, self.num_beams, self.sync_every = engine, int(num_beams), sync_every
+        cap = engine.max_batch // self.num_beams
+        if engine.max_batch <= 4:  # register GEMVs: one group
+            cap = min(cap, 1)
+        self.max_groups = max(1, min(cap, max_groups or cap))
+        assert self.max_groups * self.num_beams <= engine.max_batch, (self.max_groups, self.num_beams, engine.max_batch)
+        self.stats = dict(decode_calls=0, group_steps=0, busy_group_steps=0, refills=0)
+
+    def run(self, segments, on_done, fixed_length=False, **sampler):
+        """Decode every segment; `on_done(segment, ids, score)` as each finishes: ids = the best hypothesis as
+        `generate()` returns it (`BeamSearchScorer.finalize`: + eos when there is room)."""
+        queue = collections.deque((seg, getattr(seg, "stream", None) if getattr(seg, "stream", None) is not None else i) for i, seg in enumerate(segments))
+        groups = [None] * self.max_groups  # [segment, steps issued]
+        begun = 0                           # groups that have held a segment (fill from 0 upwards)
+        eng, nb = self.engine, self.num_beams
+        while queue or any(g is not None for g in groups):
+            for g in range(self.max_groups):
+                if groups[g] is None and queue and g <= begun:
+                    seg, stream = queue.popleft()
+                    eng.prefill(g * nb, seg.embeds, seg.n_left_pad)
+                    eng.beam_begin(nb, group=g, rng_stream=stream)
+                    if g < begun:
+                        self.stats["refills"] += 1
+                    begun = max(begun, g + 1)
+                    groups[g] = [seg, 0]
+            live = [g for g in range(self.max_groups) if groups[g] is not None]
+            n_groups = max(live) + 1
+            for g in range(n_groups):
+                if groups[g] is None:
+                    eng.beam_park(g)  # nothing queued for it: a no-op under the live ones
+            steps = min([self.sync_every] + [groups[g][0].max_new - groups[g][1] for g in live])
+            if steps > 0:
+                eng.beam_decode(steps, groups=n_groups, suppress_stop=fixed_length, **sampler)
+                self.stats["decode_calls"] += 1
+                self.stats["group_steps"] += n_groups * steps
+                self.stats["busy_group_steps"] += len(live) * steps
+            for g in live:
+                seg = groups[g][0]
+                groups[g][1] += steps
+                ids, done, score = eng.beam_read(seg.max_new, group=g)[:3]
+                if done or groups[g][1] >= seg.max_new:
+                    on_done(seg, np.asarray(ids), score)
+                    groups[g] = None
         return self.stats
