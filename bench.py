@@ -84,9 +84,10 @@ def parse(argv=None):
     ap.add_argument("--concurrency", type=int, default=1, help="requests in flight per GPU: their segments share the decode slots through the "
                     "continuous-batching scheduler (row N3); 1 = BASELINE configs[1], the judged line")
     ap.add_argument("--no-cond", action="store_true", help="leave the conditioning encoders out of the timed region (feed a synthetic conds_latent)")
-    ap.add_argument("--decode", default="greedy", choices=["greedy", "beam", "sample"], help="greedy: BASELINE configs[1] (the judged line); beam: the "
-                    "served default -- 3-beam beam-sample, top_k 30, top_p 0.8, temperature 0.8 -- one segment at a time; sample: BASELINE configs[2] -- "
-                    "top-p sampling without beams (top_p 0.8, top_k 30, temperature 0.8), both segments together")
+    ap.add_argument("--decode", default="greedy", choices=["greedy", "beam", "beam-turn", "sample"], help="greedy: BASELINE configs[1] (the judged line); beam: the "
+                    "served default -- 3-beam beam-sample, top_k 30, top_p 0.8, temperature 0.8 -- every segment a beam group, the groups stepping together "
+                    "on the wide engine (what infer() runs); beam-turn: the same, one segment at a time on the register engine (the reference's order); "
+                    "sample: BASELINE configs[2] -- top-p sampling without beams (top_p 0.8, top_k 30, temperature 0.8), both segments together")
     ap.add_argument("--emo-alpha", type=float, default=None, help="BASELINE configs[2]: a separate emotion prompt (5 s, 249 w2v-bert frames) merged with this "
                     "alpha (0.7) in the conditioning encoders (merge_emovec, model_v2.py:742-747)")
     ap.add_argument("--bigvgan-only", action="store_true", help="BASELINE configs[4]: 1000-frame random mel -> waveform microbench (20 warm-up + 100 timed)")
@@ -237,13 +238,11 @@ def run_request(wl, hp, pr, texts, n_codes, mode, R=1, acc=None):
         print(f"[detail] conditioning {1e3 * (tc_ - t0):.2f} ms, prepare_gpt_inputs {1e3 * (tp_ - tc_):.2f} ms", file=sys.stderr)
     if R > 1:
         many = hp.generate_many([(e, p, n_codes) for _ in range(R) for (e, p) in prompts], fixed_length=True, repetition_penalty=10.0)
-    elif mode == "beam":  # served default (infer_v2.py:598-606): the beams of one segment occupy the slots, segments in turn
-        many = []
-        for e, p in prompts:
-            hp.gpt.prefill(0, e, p)
-            hp.gpt.beam_begin(3)
-            hp.gpt.beam_decode(n_codes, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=True, seed=7)
-            many.append(hp.gpt.beam_read(n_codes)[0][:n_codes])
+    elif mode in ("beam", "beam-turn"):
+        # served default (infer_v2.py:598-606): each segment a 3-beam group; the engine's groups step together ("beam": wide engine,
+        # 3 x segments slots) or the one group of a register engine takes the segments in turn ("beam-turn", the reference's order)
+        many = [c[:n_codes] for c in hp.generate_beams_many([(e, p, n_codes) for (e, p) in prompts], num_beams=3, fixed_length=True, repetition_penalty=10.0,
+                                                            temperature=0.8, top_k=30, top_p=0.8, seed=7)]
     elif len(prompts) <= hp.gpt.max_batch:
         samp = dict(do_sample=True, temperature=0.8, top_k=30, top_p=0.8, seed=7) if mode == "sample" else {}
         many = hp.generate(prompts, n_codes, repetition_penalty=10.0, fixed_length=True, **samp)
@@ -317,7 +316,7 @@ def main():
     else:
         P, max_codes = 34 + n_tok + 2 + 1, n_codes
         # R requests in flight: one decode slot per segment (wide engines step up to 16 together on the matrix cores)
-        max_batch = min(slots, R * n_seg) if R > 1 else (3 if args.decode == "beam" else min(max(2, n_seg), engine_max))
+        max_batch = min(slots, R * n_seg) if R > 1 else (min(3 * n_seg, engine_max // 3 * 3) if args.decode == "beam" else 3 if args.decode == "beam-turn" else min(max(2, n_seg), engine_max))
     frames = int(max_codes * 1.72)
     hp = make_hotpath(args, dev, args.dtype, max_batch, P + max_codes + 64, frames)
 
@@ -451,7 +450,7 @@ def main():
             "bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3),
         }
         if not mixed and R == 1:
-            step_us = stage_ms["gpt_gen"] / args.steps * 1e3 / n_codes / (n_seg if args.decode == "beam" else 1)
+            step_us = stage_ms["gpt_gen"] / args.steps * 1e3 / n_codes / (n_seg if args.decode == "beam-turn" else 1)
             roofline["decode_step"] = {"alg_bytes": step_bytes, "us": round(step_us, 1), "achieved_GBps": round(step_bytes / step_us / 1e3, 1),
                                        "frac": round(step_bytes / step_us / 1e3 / PEAK_HBM, 4), "kernels_per_step": 5 * L + 2,
                                        "note": "gpt_gen / codes: includes the conditioning encoders, the prefills and the host syncs (pessimistic by ~3 %)"}
@@ -495,10 +494,14 @@ def main():
                                     "TFLOPs": mb["roofline"]["achieved"], "frac": mb["roofline"]["frac"], "peak": mb["roofline"]["peak"],
                                     "frac_fp32_mfma_peak": mb["roofline"]["frac_of_fp32_mfma_peak"]}
         one_audio = audio_seconds([n_codes] * n_seg)
-        for name, dtype, mode, mb_ in (("beam3_bf16", "bf16", "beam", 3), ("greedy_fp32", "f32", "greedy", min(max(2, n_seg), engine_max))):
+        for name, dtype, mode, mb_ in (("beam3_bf16", "bf16", "beam", min(3 * n_seg, engine_max // 3 * 3)), ("beam3_bf16_segments_in_turn", "bf16", "beam-turn", 3),
+                                       ("greedy_fp32", "f32", "greedy", min(max(2, n_seg), engine_max))):
             log(f"extra: {name} request")
             hp2 = make_hotpath(args, dev, dtype, mb_, P + n_codes + 64, frames, share=hp)
-            hp2.gpt.load_state_dict(Wg)
+            if dtype == args.dtype:
+                hp2.gpt.share_arena(hp.gpt)  # another engine shape over the same device weights
+            else:
+                hp2.gpt.load_state_dict(Wg)
             acc = {k: 0.0 for k in stage_ms}
             run_request(wl, hp2, pr, texts, n_codes, mode, 1, dict(acc))
             torch.cuda.synchronize()
@@ -510,7 +513,8 @@ def main():
             dt = (time.perf_counter() - tq) / reps
             extra[name] = {"rtf": round(dt / one_audio, 5), "audio_seconds_per_second": round(one_audio / dt, 2), "ms_per_request": round(dt * 1e3, 1),
                            "stage_ms": {k: round(v / reps, 1) for k, v in acc.items()},
-                           "decode_us_per_step": round(acc["gpt_gen"] / reps * 1e3 / n_codes / (n_seg if mode == "beam" else 1), 1)}
+                           "decode_us_per_step": round(acc["gpt_gen"] / reps * 1e3 / n_codes / (n_seg if mode == "beam-turn" else 1), 1),
+                           "sequences_per_step": {"beam": 3 * n_seg, "beam-turn": 3}.get(mode, n_seg)}
             del hp2
             torch.cuda.empty_cache()
         log("extra: decode step per batch size")
@@ -520,7 +524,7 @@ def main():
             if kind == "wide_mfma" and engine_max <= 4:
                 continue
             hpB = make_hotpath(args, dev, "bf16", mb_, P + 64 + 512, 64, share=hp)
-            hpB.gpt.load_state_dict(Wg)
+            hpB.gpt.share_arena(hp.gpt)
             extra["decode_step_by_batch"][kind] = decode_step_by_batch(hpB, P, [b for b in bs if b <= mb_])
             del hpB
             torch.cuda.empty_cache()
@@ -612,7 +616,8 @@ def main():
                         + (f"emotion prompt merged at alpha {args.emo_alpha}, " if args.emo_alpha is not None else "")
                         + (f"greedy fixed-length decode {n_codes} codes/segment batched B={min(n_seg, max_batch)}, " if args.decode == "greedy" else
                            f"top-p sampling (top_p 0.8, top_k 30, T 0.8, theta 10) fixed-length decode {n_codes} codes/segment batched B={min(n_seg, max_batch)}, " if args.decode == "sample" else
-                           f"3-beam beam-sample (top_k 30, top_p 0.8, T 0.8, theta 10) fixed-length decode {n_codes} codes/segment, segments in turn, ")
+                           f"3-beam beam-sample (top_k 30, top_p 0.8, T 0.8, theta 10) fixed-length decode {n_codes} codes/segment, "
+                           + ("the segments' beam groups stepping together (wide engine), " if args.decode == "beam" else "segments in turn, "))
                         + "latent GPT forward, "
                         + ("s2mel (length regulator + 25-step CFM/DiT, PyTorch-ROCm glue, fp32, 430-frame prompt), " if use_s2mel else "s2mel skipped (synthetic mel), ")
                         + f"BigVGAN {frames} frames/segment -> {audio_s / R:.2f} s audio; the per-prompt features the reference caches (w2v-bert, CAM++, "

@@ -189,6 +189,10 @@ int ixtts_gpt_set_tensor(ixtts_gpt* h, const char* name, const float* data_host,
 int ixtts_gpt_finalize(ixtts_gpt* h);
 int ixtts_gpt_arena(ixtts_gpt* h, void** ptr_dev, size_t* bytes);
 int ixtts_gpt_adopt_arena(ixtts_gpt* h);
+/* A second engine over the SAME device weights (one worker holds a register engine for single sequences / one beam group and a
+ * wide engine for several beam groups; the reference has one model object, model_v2.py:433-446): `h` gives up its own arena and
+ * reads `owner`'s.  Same model shape and weight type; `owner` must be finalized and outlive `h`. */
+int ixtts_gpt_share_arena(ixtts_gpt* h, ixtts_gpt* owner);
 
 /* `store_mel_emb(embeds)` + the prefill forward of generate() for sequence slot `b`
  * (model_v2.py:87-88,144-155): embeds_dev [P-1, D] fp32 = [pad][conds 34][text L+2] rows,

@@ -457,7 +457,10 @@ def beam_replay(oracle, embeds, mask, step_tokens, step_src, theta=10.0, tempera
     """A GIVEN beam-sample run (per step: the token each new beam took and the beam it continues) pushed through the oracle:
     what `_beam_search` would have scored it.  Returns a list with, per step, `inc` [num_beams] = the processed log-probability
     of (source beam, token) -- the beam score's increment (-inf where the oracle's TopK / TopP removed that token), `kept`
-    [num_beams] bools, and `logits` [num_beams, V] after the steps in `keep_logits`.  The beams step as one batch."""
+    [num_beams] bools, `amp` [num_beams] = d(increment) / d(log-probability) of that pair through the processors (theta /
+    temperature for a token of the history, whose negative log-probability the repetition penalty multiplies by theta; 1 /
+    temperature otherwise) -- what a log-probability error is amplified by -- and `logits` [num_beams, V] after the steps in
+    `keep_logits`.  The beams step as one batch."""
     P = len(mask)
     prefix = [1] * (P - 1) + [start_mel]
     nb = len(step_tokens[0])
@@ -471,7 +474,9 @@ def beam_replay(oracle, embeds, mask, step_tokens, step_src, theta=10.0, tempera
         scores = beam_scores_step(logits, [prefix + h for h in hist], [0.0] * nb, theta, temperature, top_k, top_p,
                                   suppress=[stop_mel] if suppress_stop else None)
         inc = [float(scores[src[j], toks[j]]) for j in range(nb)]
-        rec = dict(inc=inc, kept=[v != float("-inf") for v in inc])
+        t_ = temperature if temperature else 1.0
+        amp = [((theta if theta else 1.0) if toks[j] in set(prefix + hist[src[j]]) else 1.0) / t_ for j in range(nb)]
+        rec = dict(inc=inc, kept=[v != float("-inf") for v in inc], amp=amp)
         hist = [hist[src[j]] + [toks[j]] for j in range(nb)]
         idx = torch.as_tensor(src, dtype=torch.long)
         lg, pasts = oracle.decode_step_batch(toks, step, [(k.index_select(0, idx), v.index_select(0, idx)) for k, v in pasts], mask)

@@ -311,7 +311,7 @@ def test_infer_many_shares_the_decode_slots(tts_from_dir):
     reqs = [dict(spk_audio_prompt=wav_a, text="Hello world, this is a test. 你好世界！"),
             dict(spk_audio_prompt=wav_b, text="Short."),
             dict(spk_audio_prompt=wav_a, text="Vector.", emo_vector=[0.3, 0, 0, 0, 0, 0, 0.2, 0.1])]
-    outs = m.infer_many(reqs, decode_slots=4, top_k=1, max_mel_tokens=20)
+    outs = m.infer_many(reqs, decode_slots=4, num_beams=1, top_k=1, max_mel_tokens=20)
     assert len(outs) == 3 and m.last_timing["audio_length"] > 0
     for rq, (sr, pcm) in zip(reqs, outs):
         assert sr == 22050 and pcm.dtype == np.int16 and pcm.ndim == 2 and pcm.shape[1] == 1
@@ -344,3 +344,80 @@ def test_http_batched_mode_over_the_real_pipeline(tts_from_dir, monkeypatch):
             with wave.open(io.BytesIO(bytes.fromhex(r.json()["audio_hex"]))) as w:
                 assert w.getframerate() == 22050 and w.getnframes() > 0
 
+
+
+@pytest.fixture(scope="module")
+def tts_bf16_from_dir(tmp_path_factory):
+    """The same synthetic model_dir in the throughput mode (use_fp16 -> bf16 GPT): beam groups run on the wide engine."""
+    import synthetic_model_dir as SM
+    from indextts.infer_v2 import IndexTTS2
+    from voice_tts_amd.front import TextNormalizer, TextTokenizer
+
+    root = str(tmp_path_factory.mktemp("model_dir_bf16"))
+    cfg_path, cfg = SM.write_model_dir(root)
+
+    class Same:
+        def normalize(self, s):
+            return s
+
+    tok = TextTokenizer(root + "/bpe.model", TextNormalizer(Same(), Same()))
+    m = IndexTTS2(cfg_path=cfg_path, model_dir=root, use_fp16=True, device="cuda:0", tokenizer=tok, max_seq=256, max_frames=256)
+    return m, SM
+
+
+def test_served_default_decodes_the_segments_beam_groups_together(tts_bf16_from_dir, monkeypatch):
+    """`infer()` with its defaults (num_beams=3 beam-sample, infer_v2.py:598-606) on a text of several segments: every segment
+    is a beam group and the groups step together on the wide engine (one scheduler run, 3 x segments slots); with
+    IXTTS_BEAM_GROUPS=1 the segments go one after another through the register engine, as the reference runs them."""
+    from voice_tts_amd import scheduler as SCH
+
+    m, SM = tts_bf16_from_dir
+    wav = SM.synthetic_wav_bytes(1.5, 24000)
+    text = "Hello world, this is a test. 你好世界！ One more sentence follows here. And a last one."
+    runs = []
+    real_run = SCH.BeamGroupScheduler.run
+
+    def spy(self, segments, on_done, **kw):
+        st = real_run(self, segments, on_done, **kw)
+        runs.append((self.engine.max_batch, self.max_groups, len(segments), dict(st)))
+        return st
+
+    monkeypatch.setattr(SCH.BeamGroupScheduler, "run", spy)
+    sr, pcm = m.infer(wav, text, None, max_text_tokens_per_segment=20, max_mel_tokens=24, seed=4)
+    assert sr == 22050 and pcm.dtype == np.int16 and pcm.shape[1] == 1 and pcm.shape[0] > 0
+    assert len(runs) == 1 and runs[0][0] == 15 and runs[0][2] >= 3, runs  # one run, wide engine, all segments in it
+    assert runs[0][3]["busy_group_steps"] > runs[0][3]["decode_calls"] * 8, runs  # several groups per step
+    n_seg = runs[0][2]
+    # same request, groups off: the register engine, segment after segment -- same amount of audio structure (segments + silences)
+    monkeypatch.setenv("IXTTS_BEAM_GROUPS", "1")
+    sr2, pcm2 = m.infer(wav, text, None, max_text_tokens_per_segment=20, max_mel_tokens=24, seed=4)
+    assert len(runs) == 1 and sr2 == 22050 and pcm2.shape[0] > 0
+    # every segment yields between 1 and 24 codes -> frames; 200 ms of silence between segments
+    sil = (n_seg - 1) * int(22050 * 0.2)
+    for p in (pcm, pcm2):
+        assert sil + n_seg * 256 <= p.shape[0] <= sil + n_seg * int(24 * 1.72) * 256
+
+
+def test_infer_many_keeps_the_beams_and_fails_requests_alone(tts_bf16_from_dir):
+    """`infer_many` with the served defaults: segments of all requests as beam groups on the wide engine; a request whose prompt
+    audio cannot be decoded gets its exception back in its slot, the others their audio."""
+    m, SM = tts_bf16_from_dir
+    wav_a, wav_b = SM.synthetic_wav_bytes(1.5, 24000), SM.synthetic_wav_bytes(1.0, 16000, seed=1)
+    reqs = [dict(spk_audio_prompt=wav_a, text="Hello world, this is a test."),
+            dict(spk_audio_prompt=b"this is not audio at all", text="Broken prompt."),
+            dict(spk_audio_prompt=wav_b, text="Short."),
+            dict(spk_audio_prompt=wav_a, text="")]
+    outs = m.infer_many(reqs, decode_slots=9, max_mel_tokens=16, seed=2)
+    assert len(outs) == 4
+    assert isinstance(outs[1], Exception) and outs[3] is None
+    for o in (outs[0], outs[2]):
+        assert isinstance(o, tuple) and o[0] == 22050 and o[1].dtype == np.int16 and o[1].shape[0] > 0
+    assert 9 in m._engines  # three groups of three beams
+    # a code outside the semantic codebook is refused on the host, for that request only
+    real = m.s2mel.W["quantizer.codebook.weight"]
+    m.s2mel.W["quantizer.codebook.weight"] = real[:4]
+    try:
+        outs = m.infer_many(reqs[:1], decode_slots=9, max_mel_tokens=8, seed=2)
+        assert isinstance(outs[0], ValueError) and "codebook" in str(outs[0])
+    finally:
+        m.s2mel.W["quantizer.codebook.weight"] = real

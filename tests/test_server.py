@@ -163,3 +163,35 @@ def test_opt_in_request_batching_replaces_the_lock(monkeypatch):
                 assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 22050)
                 assert abs(w.getnframes() / 22050 - body["audio_length"]) < 1e-9
         assert c.post("/tts", json={"text": "boom", "spk_audio": HEX}).status_code == 500
+
+
+def test_batched_requests_fail_alone(monkeypatch):
+    """One malformed request in a batch (its entry of `infer_many`'s result is the exception it raised) answers 500; the two
+    good requests batched with it are served."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+
+    class BatchStub(StubTTS):
+        def __init__(self):
+            super().__init__()
+            self.batches = []
+
+        def infer_many(self, requests, decode_slots=8, **kw):
+            self.batches.append([r["text"] for r in requests])
+            return [ValueError("speaker audio is not RIFF/WAVE") if r["text"] == "bad" else (22050, np.zeros((2205, 1), np.int16)) for r in requests]
+
+    monkeypatch.setenv("IXTTS_BATCH_SLOTS", "4")
+    monkeypatch.setenv("IXTTS_BATCH_WINDOW_MS", "300")
+    stub = BatchStub()
+    with TestClient(create_app(lambda: stub)) as c:
+        barrier = threading.Barrier(3)
+
+        def post(t):
+            barrier.wait()
+            return c.post("/tts", json={"text": t, "spk_audio": HEX})
+
+        with ThreadPoolExecutor(3) as ex:
+            rs = dict(zip(["good1", "bad", "good2"], ex.map(post, ["good1", "bad", "good2"])))
+        assert any(len(b) == 3 for b in stub.batches), stub.batches  # the three really shared a batch
+        assert rs["good1"].status_code == 200 and rs["good2"].status_code == 200
+        assert rs["bad"].status_code == 500 and "RIFF" in rs["bad"].text

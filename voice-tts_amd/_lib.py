@@ -68,6 +68,7 @@ SYMBOLS = {
     "ixtts_gpt_finalize": (C.c_int, [_P]),
     "ixtts_gpt_arena": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "ixtts_gpt_adopt_arena": (C.c_int, [_P]),
+    "ixtts_gpt_share_arena": (C.c_int, [_P, _P]),
     "ixtts_gpt_prefill": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P]),
     "ixtts_gpt_decode": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(SamplerCfg), _P]),
     "ixtts_gpt_read": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),

@@ -66,6 +66,7 @@ struct ixtts_gpt {
   size_t esize;
   uint8_t* arena = nullptr;
   size_t arena_bytes = 0;
+  bool arena_borrowed = false;  // ixtts_gpt_share_arena: the arena belongs to another handle
   std::vector<ixtts::LayerOff> lo;
   size_t lnf_w, lnf_b, fn_w, fn_b, whead, bhead, mel_emb, mel_pos;
   std::map<std::string, ixtts::TDesc> tens;

@@ -640,6 +640,27 @@ extern "C" int ixtts_gpt_adopt_arena(ixtts_gpt* h) {
   return derive_fused_mlp(h);
 }
 
+// A second engine over the SAME weights (e.g. the wide beam-group engine beside the register engine of one worker): `h`
+// drops its own arena and reads `owner`'s, which must be finalized, of the same shape and type, and outlive `h`.
+extern "C" int ixtts_gpt_share_arena(ixtts_gpt* h, ixtts_gpt* owner) {
+  IX_ARG(h && owner && h != owner, "gpt_share_arena: bad handles");
+  IX_ARG(owner->finalized && !owner->arena_borrowed, "gpt_share_arena: the owner must hold finalized weights of its own");
+  IX_ARG(h->D == owner->D && h->L == owner->L && h->H == owner->H && h->V == owner->V && h->esize == owner->esize &&
+             h->cfg.n_mel_pos == owner->cfg.n_mel_pos && h->arena_bytes == owner->arena_bytes,
+         "gpt_share_arena: the two engines differ in shape or weight type");
+  IX_HIP(hipDeviceSynchronize());
+  if (h->arena && !h->arena_borrowed) hipFree(h->arena);
+  h->arena = owner->arena;
+  h->arena_borrowed = true;
+  for (auto& kv : h->tens) kv.second.set = true;
+  if (h->stage) {
+    hipFree(h->stage);
+    h->stage = nullptr;
+  }
+  h->finalized = true;
+  return derive_fused_mlp(h);
+}
+
 #define NEED_READY(h, who)                                       \
   do {                                                           \
     IX_ARG(h, who ": null handle");                              \
@@ -1108,6 +1129,7 @@ extern "C" int ixtts_gpt_destroy(ixtts_gpt* h) {
     }
   }
   if (h->cap_stream) hipStreamDestroy(h->cap_stream);
+  if (h->arena_borrowed) h->arena = nullptr;  // the owner frees it
   void* ptrs[] = {h->arena, h->stage, h->kc, h->vc, h->h, h->q, h->ff, h->att, h->part, h->logits, h->rowbuf, h->cur_len, h->gen_count,
                   h->prompt_len, h->valid_from, h->finished, h->forced, h->tokens, h->seen, h->d_samp, h->probs, h->scratch, h->beam_scores, h->hyp_score, h->hyp_worst, h->beam_src, h->hyp_len,
                   h->n_hyp, h->beam_done, h->beam_forced_flag, h->beam_forced, h->hyp_tok, h->beam_cand_v, h->beam_cand_i, h->beam_cand_n, h->beam_lcp, h->beam_stream,

@@ -72,6 +72,15 @@ class GptEngine:
         _lib.check(_lib.lib().ixtts_gpt_adopt_arena(self._h), "ixtts_gpt_adopt_arena")
         self._loaded = True
 
+    def share_arena(self, owner):
+        """Read `owner`'s device weights instead of holding a copy (same model, same dtype): a second engine shape -- e.g. the
+        wide beam-group engine beside the register engine -- costs its KV cache only."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ixtts_gpt_share_arena(self._h, owner._h), "ixtts_gpt_share_arena")
+        self._owner = owner  # keep it alive
+        self._loaded = True
+        return self
+
     # ------------------------------------------------------------------ low level
     def _stream(self):
         return _lib.current_stream_ptr()

@@ -182,9 +182,7 @@ class IndexTTS2:
         self.bigvgan = BigVGAN(bcfg, use_cuda_kernel=True, max_frames=max_frames, device=self.device)
         self.gpt.load_state_dict(gpt_state_dict)
         self.bigvgan.load_state_dict(bigvgan_state_dict)
-        self._gpt_tensors = {k: v for k, v in gpt_state_dict.items() if k.startswith(("gpt.h.", "gpt.ln_f.", "final_norm.", "mel_head.", "mel_embedding.",
-                                                                                       "mel_pos_embedding."))}  # for infer_many's engine
-        self._many = None
+        self._engines = {}  # further engine shapes over the same device weights, by slot count (infer_many, beam groups)
         D = gcfg["model_dim"]
         self.text_embedding = gpt_state_dict["text_embedding.weight"].to(self.device, torch.float32)
         self.text_pos_embedding = gpt_state_dict["text_pos_embedding.emb.weight"].to(self.device, torch.float32)
@@ -374,111 +372,164 @@ class IndexTTS2:
         from . import _lib
 
         slots = max(1, min(int(slots), _lib.max_batch() if self.use_fp16 else 4))
-        if self._many is None or self._many.max_batch != slots:
-            self._many = GptEngine(self.gpt_cfg, dtype="bf16" if self.use_fp16 else "f32", max_seq=self.gpt.max_seq, max_batch=slots, device=self.device)
-            self._many.load_state_dict(self._gpt_tensors)
-        return self._many
+        if slots not in self._engines:
+            # a second engine SHAPE over the same device weights (ixtts_gpt_share_arena): it costs its KV cache only
+            eng = GptEngine(self.gpt_cfg, dtype="bf16" if self.use_fp16 else "f32", max_seq=self.gpt.max_seq, max_batch=slots, device=self.device)
+            self._engines[slots] = eng.share_arena(self.gpt)
+        return self._engines[slots]
+
+    def _beam_group_engine(self, num_beams, n_segments):
+        """The engine several beam groups step together on: wide (5..16 slots on the bf16 matrix cores) when the model runs in
+        bf16 and there is more than one segment to decode, else None (one group at a time on the register engine, as the
+        reference decodes: segment after segment).  `IXTTS_BEAM_GROUPS` caps the groups (0 / 1: off)."""
+        from . import _lib
+
+        cap = int(os.environ.get("IXTTS_BEAM_GROUPS", "5"))
+        groups = min(cap, _lib.max_batch() // num_beams, n_segments)
+        if not self.use_fp16 or groups < 2 or groups * num_beams <= 4:
+            return None
+        want = min(cap, _lib.max_batch() // num_beams) * num_beams  # one engine shape per worker, whatever the request's segment count
+        eng = self._many_engine(want)
+        return eng if eng.max_batch >= 2 * num_beams else None
+
+    def _check_codes(self, codes):
+        """The reference would index the semantic codec's codebook out of range with such a code (a device-side assert on a
+        GPU, which takes the worker's context with it): refuse on the host instead."""
+        if self.s2mel is not None and codes.numel():
+            rows = self.s2mel.W["quantizer.codebook.weight"].shape[0]
+            top = int(codes.max())
+            if top >= rows:
+                raise ValueError(f"mel code {top} outside the semantic codec's codebook ({rows} entries)")
 
     @torch.no_grad()
     def infer_many(self, requests, interval_silence=200, max_text_tokens_per_segment=120, decode_slots=8, **generation_kwargs):
         """Several `/tts` requests served TOGETHER (the worker's global lock, server.py:25,384, replaced by the
         decode scheduler): every request's segments share the decode slots -- the weights are read once per step for all of them
         -- and the post-decode stages run per segment as in `infer`.  Each request is a dict with `spk_audio_prompt`, `text` and
-        optionally `emo_audio_prompt`, `emo_alpha`, `emo_vector`, `use_random`.  Decoding is sampling WITHOUT beams (the beams of
-        one request would take the slots the others use; `num_beams` is ignored), deterministic argmax when `top_k == 1`; the
-        other generation kwargs and defaults are `infer`'s.  Returns one `(22050, int16 [N, 1])` (or None: empty text) per request."""
-        from .scheduler import DecodeScheduler, Segment
+        optionally `emo_audio_prompt`, `emo_alpha`, `emo_vector`, `use_random`.  Generation kwargs and defaults are `infer`'s:
+        with `num_beams > 1` (the served default, 3) every segment is a beam GROUP and floor(decode_slots / num_beams) groups step
+        together (bf16 engines; an fp32 model decodes group after group); `num_beams=1` samples without beams, one slot per
+        segment (argmax when `top_k == 1`).  Returns one entry per request: `(22050, int16 [N, 1])`, None (empty text), or the
+        EXCEPTION that request raised (bad prompt audio, a code outside the codebook ...) -- one request's failure leaves the
+        others of the batch alone."""
+        from . import _lib
+        from .scheduler import BeamGroupScheduler, DecodeScheduler, Segment
 
         generation_kwargs.pop("do_sample", True)
         top_p = generation_kwargs.pop("top_p", 0.8)
         top_k = generation_kwargs.pop("top_k", 30)
         temperature = generation_kwargs.pop("temperature", 0.8)
-        generation_kwargs.pop("num_beams", None)
-        generation_kwargs.pop("length_penalty", None)
+        num_beams = int(generation_kwargs.pop("num_beams", 3))
+        length_penalty = generation_kwargs.pop("length_penalty", 0.0)
         repetition_penalty = generation_kwargs.pop("repetition_penalty", 10.0)
         max_mel_tokens = generation_kwargs.pop("max_mel_tokens", 1500)
+        typical_mass = float(generation_kwargs.get("typical_mass", 0.9)) if generation_kwargs.get("typical_sampling") else 0.0
         speaker_fn = self._stage("speaker", self.prompt.speaker if self.prompt else None)
         emotion_fn = self._stage("emotion", self.prompt.emotion if self.prompt else None)
-        eng = self._many_engine(decode_slots)
+        if num_beams > 1:
+            if not (2 <= num_beams <= 4 and 1 <= top_k <= 128):
+                raise NotImplementedError("beam-sample on the device: 2 <= num_beams <= 4, 1 <= top_k <= 128")
+            groups = max(1, min(int(decode_slots), _lib.max_batch()) // num_beams)
+            eng = self._many_engine(groups * num_beams) if self.use_fp16 and groups * num_beams > 4 else self.gpt
+        else:
+            eng = self._many_engine(decode_slots)
         start = time.perf_counter()
-        plans, todo = [], []
+        plans, todo = [None] * len(requests), []
+        failed = {}
         for ri, rq in enumerate(requests):
-            spk_prompt, emo_prompt = rq["spk_audio_prompt"], rq.get("emo_audio_prompt")
-            emo_alpha, emo_vector = rq.get("emo_alpha", 1.0), rq.get("emo_vector")
-            if emo_vector is not None:  # infer_v2.py:476-505
-                emo_prompt = None
-                scale = max(0.0, min(1.0, emo_alpha))
-                if scale != 1.0:
-                    emo_vector = [int(x * scale * 10000) / 10000 for x in emo_vector]
-            emo_is_spk = emo_prompt is None  # (then both emotion-encoder passes see the same features: computed once)
-            if emo_prompt is None:
-                emo_prompt, emo_alpha = spk_prompt, 1.0
-            if self.cache_spk is None or not _same_prompt(self.cache_spk_audio_prompt, spk_prompt):
-                self.cache_spk, self.cache_spk_audio_prompt = speaker_fn(spk_prompt), spk_prompt
-            spk = self.cache_spk
-            if self.cache_emo_cond is None or not _same_prompt(self.cache_emo_audio_prompt, emo_prompt):
-                self.cache_emo_cond, self.cache_emo_audio_prompt = emotion_fn(emo_prompt), emo_prompt
-            emo_cond = self.cache_emo_cond
-            if self.cond is not None:
-                cond32, emovec = self.cond.encode_prompt(spk["spk_cond_emb"], None if emo_is_spk else emo_cond, emo_alpha)
-            else:
-                emovec = self._stage("merge_emovec", None)(spk["spk_cond_emb"], emo_cond, emo_alpha)
-                cond32 = self._stage("get_conditioning", None)(spk["spk_cond_emb"])
-            if emo_vector is not None:
-                mix = self._stage("emo_vector_mix", (lambda v, st, r: self._builtin_emo_mix(v, st, r)) if self.emo_matrix is not None else None)
-                emovec_mat, weight_sum = mix(emo_vector, spk["style"], rq.get("use_random", False))
-                emovec = emovec_mat + (1 - weight_sum) * emovec
-            cl = torch.cat((cond32 + emovec.reshape(1, -1), self.speed_emb[1:2], self.speed_emb[0:1]), 0)
-            if self.tokenizer is not None:
-                toks = self.tokenizer.tokenize(rq["text"])
-                segments = [self.tokenizer.convert_tokens_to_ids(sent) for sent in self.tokenizer.split_segments(toks, max_text_tokens_per_segment)]
-            else:
-                segments = self._stage("tokenize", None)(rq["text"], max_text_tokens_per_segment, 0)
-            plans.append(dict(spk=spk, cl=cl, segments=segments, codes=[None] * len(segments)))
-            for si, ids in enumerate(segments):
-                tt = torch.as_tensor(ids, dtype=torch.int32, device=self.device).reshape(-1)
-                fake, embeds, mask = self._prepare_gpt_inputs(cl, tt)
-                n_pad = int((mask == 0).sum().item())
-                max_new = max(0, min(max_mel_tokens, eng.max_seq - fake.shape[1] - 2, self.gpt_cfg["max_mel_tokens"] - 1))
-                todo.append(Segment(ri, si, embeds[0], n_pad, max_new))
-        greedy = top_k == 1
-        if todo:
+            try:
+                spk_prompt, emo_prompt = rq["spk_audio_prompt"], rq.get("emo_audio_prompt")
+                emo_alpha, emo_vector = rq.get("emo_alpha", 1.0), rq.get("emo_vector")
+                if emo_vector is not None:  # infer_v2.py:476-505
+                    emo_prompt = None
+                    scale = max(0.0, min(1.0, emo_alpha))
+                    if scale != 1.0:
+                        emo_vector = [int(x * scale * 10000) / 10000 for x in emo_vector]
+                emo_is_spk = emo_prompt is None  # (then both emotion-encoder passes see the same features: computed once)
+                if emo_prompt is None:
+                    emo_prompt, emo_alpha = spk_prompt, 1.0
+                if self.cache_spk is None or not _same_prompt(self.cache_spk_audio_prompt, spk_prompt):
+                    self.cache_spk, self.cache_spk_audio_prompt = None, None  # (a failing encode must not leave a stale pair behind)
+                    self.cache_spk, self.cache_spk_audio_prompt = speaker_fn(spk_prompt), spk_prompt
+                spk = self.cache_spk
+                if self.cache_emo_cond is None or not _same_prompt(self.cache_emo_audio_prompt, emo_prompt):
+                    self.cache_emo_cond, self.cache_emo_audio_prompt = None, None
+                    self.cache_emo_cond, self.cache_emo_audio_prompt = emotion_fn(emo_prompt), emo_prompt
+                emo_cond = self.cache_emo_cond
+                if self.cond is not None:
+                    cond32, emovec = self.cond.encode_prompt(spk["spk_cond_emb"], None if emo_is_spk else emo_cond, emo_alpha)
+                else:
+                    emovec = self._stage("merge_emovec", None)(spk["spk_cond_emb"], emo_cond, emo_alpha)
+                    cond32 = self._stage("get_conditioning", None)(spk["spk_cond_emb"])
+                if emo_vector is not None:
+                    mix = self._stage("emo_vector_mix", (lambda v, st, r: self._builtin_emo_mix(v, st, r)) if self.emo_matrix is not None else None)
+                    emovec_mat, weight_sum = mix(emo_vector, spk["style"], rq.get("use_random", False))
+                    emovec = emovec_mat + (1 - weight_sum) * emovec
+                cl = torch.cat((cond32 + emovec.reshape(1, -1), self.speed_emb[1:2], self.speed_emb[0:1]), 0)
+                if self.tokenizer is not None:
+                    toks = self.tokenizer.tokenize(rq["text"])
+                    segments = [self.tokenizer.convert_tokens_to_ids(sent) for sent in self.tokenizer.split_segments(toks, max_text_tokens_per_segment)]
+                else:
+                    segments = self._stage("tokenize", None)(rq["text"], max_text_tokens_per_segment, 0)
+                mine = []
+                for si, ids in enumerate(segments):
+                    tt = torch.as_tensor(ids, dtype=torch.int32, device=self.device).reshape(-1)
+                    fake, embeds, mask = self._prepare_gpt_inputs(cl, tt)
+                    n_pad = int((mask == 0).sum().item())
+                    max_new = max(0, min(max_mel_tokens, eng.max_seq - fake.shape[1] - 2, self.gpt_cfg["max_mel_tokens"] - 1))
+                    mine.append(Segment(ri, si, embeds[0], n_pad, max_new))
+                plans[ri] = dict(spk=spk, cl=cl, segments=segments, codes=[None] * len(segments))
+                todo += mine  # only once the whole request is known to be well-formed
+            except Exception as e:  # this request only
+                failed[ri] = e
+        sampler = dict(repetition_penalty=repetition_penalty, temperature=temperature, top_k=top_k, top_p=top_p, seed=int(generation_kwargs.get("seed", 0)),
+                       typical_mass=typical_mass)
+        if todo and num_beams > 1:
+            BeamGroupScheduler(eng, num_beams).run(todo, lambda seg, ids, score: plans[seg.request]["codes"].__setitem__(seg.index, ids),
+                                                   length_penalty=length_penalty, **sampler)
+        elif todo:
             DecodeScheduler(eng, eng.max_batch, self.stop_mel_token).run(
-                todo, lambda seg, ids: plans[seg.request]["codes"].__setitem__(seg.index, ids), repetition_penalty=repetition_penalty,
-                temperature=temperature, top_k=top_k, top_p=top_p, do_sample=not greedy, seed=int(generation_kwargs.get("seed", 0)))
+                todo, lambda seg, ids: plans[seg.request]["codes"].__setitem__(seg.index, ids), do_sample=top_k != 1, **sampler)
         torch.cuda.synchronize(self.device)
         t_decode = time.perf_counter() - start
         out = []
-        for plan in plans:
-            wavs = []
-            for ids, seg in zip(plan["codes"], plan["segments"]):
-                row = torch.from_numpy(np.asarray(ids).astype(np.int64)).to(self.device)
-                stops = (row == self.stop_mel_token).nonzero(as_tuple=False)
-                n = int(stops[0]) if stops.numel() else row.numel()
-                if n == 0:
-                    continue
-                codes = row[:n].reshape(1, -1)
-                tt = torch.as_tensor(seg, dtype=torch.int32, device=self.device).reshape(-1)
-                t = torch.cat((tt.new_tensor([self.gpt_cfg["start_text_token"]]), tt, tt.new_tensor([self.gpt_cfg["stop_text_token"]]))).long()
-                prefix = torch.cat((plan["cl"], self.text_embedding[t] + self.text_pos_embedding[: t.numel()]), 0)
-                latent = self.gpt.latent(prefix, codes[0]).unsqueeze(0)
-                lens = torch.tensor([n], dtype=torch.long, device=self.device)
-                spk = plan["spk"]
-                if self.s2mel is not None:
-                    mel = self.s2mel(latent, codes, lens, spk["prompt_condition"], spk["ref_mel"], spk["style"], n_timesteps=25, inference_cfg_rate=0.7)
-                else:
-                    mel = self._stage("s2mel", None)(latent, codes, lens, spk)
-                wav = torch.clamp(32767 * self.bigvgan(mel.float()).squeeze().unsqueeze(0), -32767.0, 32767.0)
-                wavs.append(wav.cpu())
-            if not wavs:
-                out.append(None)
+        for ri, plan in enumerate(plans):
+            if ri in failed:
+                out.append(failed[ri])
                 continue
-            wav = torch.cat(self.insert_interval_silence(wavs, sampling_rate=22050, interval_silence=interval_silence), dim=1)
-            out.append((22050, wav.type(torch.int16).numpy().T))
+            try:
+                wavs = []
+                for ids, seg in zip(plan["codes"], plan["segments"]):
+                    row = torch.from_numpy(np.asarray(ids).astype(np.int64)).to(self.device)
+                    stops = (row == self.stop_mel_token).nonzero(as_tuple=False)
+                    n = int(stops[0]) if stops.numel() else row.numel()
+                    if n == 0:
+                        continue
+                    codes = row[:n].reshape(1, -1)
+                    self._check_codes(codes)
+                    tt = torch.as_tensor(seg, dtype=torch.int32, device=self.device).reshape(-1)
+                    t = torch.cat((tt.new_tensor([self.gpt_cfg["start_text_token"]]), tt, tt.new_tensor([self.gpt_cfg["stop_text_token"]]))).long()
+                    prefix = torch.cat((plan["cl"], self.text_embedding[t] + self.text_pos_embedding[: t.numel()]), 0)
+                    latent = self.gpt.latent(prefix, codes[0]).unsqueeze(0)
+                    lens = torch.tensor([n], dtype=torch.long, device=self.device)
+                    spk = plan["spk"]
+                    if self.s2mel is not None:
+                        mel = self.s2mel(latent, codes, lens, spk["prompt_condition"], spk["ref_mel"], spk["style"], n_timesteps=25, inference_cfg_rate=0.7)
+                    else:
+                        mel = self._stage("s2mel", None)(latent, codes, lens, spk)
+                    wav = torch.clamp(32767 * self.bigvgan(mel.float()).squeeze().unsqueeze(0), -32767.0, 32767.0)
+                    wavs.append(wav.cpu())
+                if not wavs:
+                    out.append(None)
+                    continue
+                wav = torch.cat(self.insert_interval_silence(wavs, sampling_rate=22050, interval_silence=interval_silence), dim=1)
+                out.append((22050, wav.type(torch.int16).numpy().T))
+            except Exception as e:  # this request only
+                out.append(e)
         total = time.perf_counter() - start
-        audio = sum(o[1].shape[0] for o in out if o is not None) / 22050.0
-        logger.info(f"infer_many: {len(requests)} requests, {len(todo)} segments, decode {t_decode:.2f} s, total {total:.2f} s, "
-                    f"audio {audio:.2f} s, RTF {total / max(audio, 1e-9):.4f}")
+        audio = sum(o[1].shape[0] for o in out if isinstance(o, tuple)) / 22050.0
+        logger.info(f"infer_many: {len(requests)} requests ({sum(isinstance(o, Exception) for o in out)} failed), {len(todo)} segments, "
+                    f"decode {t_decode:.2f} s, total {total:.2f} s, audio {audio:.2f} s, RTF {total / max(audio, 1e-9):.4f}")
         self.last_timing = dict(gpt_gen_time=t_decode, total=total, audio_length=audio)
         return out
 
@@ -563,7 +614,32 @@ class IndexTTS2:
         # all of them (the reference decodes segment after segment, infer_v2.py:616; tokens per segment are the same for
         # greedy; with sampling each slot draws from its own counter-based stream).  Beam search keeps one segment at a time.
         pre = None
-        if num_beams == 1 and len(segments) > 1 and not stream_return and not generation_kwargs.get("logits_processor"):
+        beam_eng = None
+        if num_beams > 1 and len(segments) > 1 and not stream_return and not generation_kwargs.get("logits_processor") and 1 <= top_k <= 128:
+            beam_eng = self._beam_group_engine(num_beams, len(segments))
+        if beam_eng is not None:
+            # The served default (num_beams=3): every segment is a beam group of num_beams slots and the groups step TOGETHER on the
+            # wide engine -- the weights are read once per step for all of them (the reference runs `inference_speech` segment after
+            # segment, infer_v2.py:616-658).  Each segment has its own scorer state and its own random stream (segment index).
+            from .scheduler import BeamGroupScheduler, Segment
+
+            m0 = time.perf_counter()
+            todo = []
+            for i, sent_ids in enumerate(segments):
+                tt = torch.as_tensor(sent_ids, dtype=torch.int32, device=self.device).reshape(-1)
+                cl = conds_for_segment()
+                fake, embeds, mask = self._prepare_gpt_inputs(cl, tt)
+                n_pad = int((mask == 0).sum().item())
+                max_new = max(0, min(max_mel_tokens, beam_eng.max_seq - fake.shape[1] - 2, self.gpt_cfg["max_mel_tokens"] - 1))
+                todo.append(Segment(0, i, embeds[0], n_pad, max_new, payload=cl, stream=i))
+            pre = [None] * len(segments)
+            BeamGroupScheduler(beam_eng, num_beams).run(
+                todo, lambda seg, ids, score: pre.__setitem__(seg.index, (ids, seg.payload)), repetition_penalty=repetition_penalty,
+                temperature=temperature, top_k=top_k, top_p=top_p, seed=int(generation_kwargs.get("seed", 0)), length_penalty=length_penalty,
+                typical_mass=float(generation_kwargs.get("typical_mass", 0.9)) if generation_kwargs.get("typical_sampling") else 0.0)
+            torch.cuda.synchronize(self.device)
+            gpt_gen_time += time.perf_counter() - m0
+        elif num_beams == 1 and len(segments) > 1 and not stream_return and not generation_kwargs.get("logits_processor"):
             from .scheduler import DecodeScheduler, Segment
 
             m0 = time.perf_counter()
@@ -625,9 +701,7 @@ class IndexTTS2:
             gpt_forward_time += time.perf_counter() - m0
 
             m0 = time.perf_counter()
-            if self.s2mel is not None and code_len and int(codes.max()) >= self.s2mel.W["quantizer.codebook.weight"].shape[0]:
-                # the reference would index its codebook out of range here (a device-side assert on a GPU): refuse on the host instead
-                raise ValueError(f"mel code {int(codes.max())} outside the semantic codec's codebook ({self.s2mel.W['quantizer.codebook.weight'].shape[0]} entries)")
+            self._check_codes(codes)
             if self.s2mel is not None:  # infer_v2.py:713-731
                 mel = self.s2mel(latent, codes, code_lens, spk["prompt_condition"], spk["ref_mel"], spk["style"],
                                  n_timesteps=25, inference_cfg_rate=0.7)

@@ -122,8 +122,8 @@ def default_model_factory():
 class RequestBatcher:
     """Opt-in replacement of the per-worker inference lock (server.py:25,384) by the decode scheduler: handlers
     queue their request; one thread takes what has arrived within `window_s` (at most `slots` requests) and serves the batch
-    through `model.infer_many` -- every request's segments share the decode slots.  Decoding in this mode is sampling without
-    beams (see `IndexTTS2.infer_many`), which is why it is not the default."""
+    through `model.infer_many` -- every request's segments share the decode slots, each segment a 3-beam group as in the
+    lock-step path (see `IndexTTS2.infer_many`).  A request that fails (bad prompt audio ...) fails alone."""
 
     def __init__(self, model, slots, window_s=0.02):
         import queue
@@ -155,8 +155,11 @@ class RequestBatcher:
             try:
                 results = self.model.infer_many([r for r, _ in batch], decode_slots=self.slots)
                 for (_, fut), res in zip(batch, results):
-                    fut.set_result(res)
-            except Exception as e:  # one failure fails the batch it was in, as the lock-step path fails its request
+                    if isinstance(res, BaseException):  # that request's own failure; the others of the batch are served
+                        fut.set_exception(res)
+                    else:
+                        fut.set_result(res)
+            except Exception as e:  # a failure of the shared decode itself fails the batch it happened in
                 for _, fut in batch:
                     if not fut.done():
                         fut.set_exception(e)
