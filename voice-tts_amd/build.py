@@ -19,6 +19,10 @@ TRACE = os.environ.get("IXTTS_TRACE") == "1"  # developer timeline build (tools/
 if TRACE:
     LIB = os.path.join(HERE, "libixtts_hip_trace.so")
     OBJ = os.path.join(HERE, "build_trace")
+VARIANT = os.environ.get("IXTTS_VARIANT")  # developer A/B builds: IXTTS_VARIANT=name IXTTS_EXP="-DX=1" -> libixtts_hip_<name>.so (load it with IXTTS_LIB)
+if VARIANT:
+    LIB = os.path.join(HERE, f"libixtts_hip_{VARIANT}.so")
+    OBJ = os.path.join(HERE, f"build_{VARIANT}")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-Wno-unused-value", "-fno-gpu-rdc",
          # first 16 kernarg dwords arrive in SGPRs with the wave (no s_load round trip before the first global loads)

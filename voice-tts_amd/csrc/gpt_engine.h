@@ -97,6 +97,7 @@ struct ixtts_gpt {
   float* h2 = nullptr;         // second residual buffer (IN_LN_PART publishes the completed stream into the other one)
   float* hc = nullptr;         // the residual buffer the launch being issued works on
   bool wide = false;       // max_batch > MAXB_REG: every decode launch of this engine takes the MFMA GEMVs, whatever n_active is
+  int pf_per = 2;          // IXTTS_PF builds (A/B lever): KiB of the next launch's weights each wave fetches ahead (IXTTS_PF_KIB)
   bool attn_split = true;  // IXTTS_ATTN=legacy turns the split-S kernel off (A/B timing, fallback test)
   int attn_bucket = ixtts::NBKT;  // bucket the graph being captured is built for
   int host_prompt_len[ixtts::MAXB + 2];

@@ -36,8 +36,38 @@ static int launch_gemv(const GemvArgs& a, hipStream_t st) {
   const int n_units = (a.N + ROWS - 1) / ROWS;
   const int grid = ceil_div(n_units, WPB * UNITS);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), 0, st, a.wt, a.xin, a.bias, a.out, a.N, a.slot0, a.out_stride, a.smax, a.kcache, a.vcache,
-                     a.cur_len, a.heads, a.nsplit, a.ln_w, a.ln_b, a.aux, a.xout IXTTS_TRACE_ARG);
+                     a.cur_len, a.heads, a.nsplit, a.ln_w, a.ln_b, a.aux, a.xout IXTTS_PF_ARGS(a) IXTTS_TRACE_ARG);
   return IXTTS_OK;
+}
+
+// IXTTS_PF builds: `a` also fetches ahead for the launch that reads matrix `next` next: which 0 qkv, 1 attn-out, 2 fc, 3 mlp-out of
+// layer l, 4 head; -1: nothing (its own matrix again: L2 hits)
+template <int D>
+static void set_prefetch(ixtts_gpt* h, GemvArgs& a, int which, int l) {
+  using DM = Dims<D>;
+  const size_t es = h->esize;
+  a.pf_ptr = a.wt;
+  a.pf_stride = 1024;
+  a.pf_per = 1;
+  a.pf_nwaves = 1;
+  if (which < 0 || h->pf_per <= 0) return;
+  size_t off = 0;
+  int rows_per_wave = 0, K = D, N = 0;
+  if (which == 4) {
+    off = h->whead; rows_per_wave = DM::R1 * DM::U_HEAD; N = h->V;
+  } else {
+    const LayerOff& o = h->lo[l];
+    switch (which) {
+      case 0: off = o.wqkv; rows_per_wave = DM::R1 * DM::U_QKV; N = 3 * D; break;
+      case 1: off = o.wo; rows_per_wave = DM::R1 * DM::U_OUT; N = D; break;
+      case 2: off = o.wfc; rows_per_wave = DM::R1 * DM::U_FC; N = 4 * D; break;
+      default: off = o.wpr; rows_per_wave = DM::R4 * DM::U_PR; K = 4 * D; N = D; break;
+    }
+  }
+  a.pf_ptr = A_PTR(off);
+  a.pf_stride = (int)(rows_per_wave * K * es);
+  a.pf_nwaves = N / rows_per_wave;  // (whole waves only: a ragged last wave is not fetched ahead)
+  a.pf_per = std::min(h->pf_per, a.pf_stride / 1024);
 }
 
 template <typename WT, typename KVT, int K, int ROWS, int UNITS, int B, int EPI, int WPB = 4>
@@ -54,7 +84,7 @@ static int launch_gemv_lds(const GemvArgs& a, hipStream_t st) {
   const int n_units = (a.N + ROWS - 1) / ROWS;
   const int grid = ceil_div(n_units, WPB * UNITS);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), smem, st, a.wt, a.xin, a.bias, a.out, a.N, a.slot0, a.out_stride, a.smax, a.kcache,
-                     a.vcache, a.cur_len, a.heads, a.nsplit, a.ln_w, a.ln_b, a.aux, a.xout IXTTS_TRACE_ARG);
+                     a.vcache, a.cur_len, a.heads, a.nsplit, a.ln_w, a.ln_b, a.aux, a.xout IXTTS_PF_ARGS(a) IXTTS_TRACE_ARG);
   return IXTTS_OK;
 }
 
@@ -77,6 +107,7 @@ static int gemv_qkv(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.cur_len = h->cur_len;
   a.smax = h->smax;
   a.heads = h->H;
+  set_prefetch<D>(h, a, 1, l);  // the attention launch in between reads no weights
   if constexpr (std::is_same<WT, bf16>::value && D == MLP_D) {
     if (h->mlp_fused) {
       if (l + 1 < h->L) a.aux = h->mlp_ctr + (size_t)l * MLP_CTR_STRIDE;  // this layer's MLP is fused: clear its counters
@@ -106,6 +137,7 @@ static int gemv_out(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.slot0 = slot0;
   a.out = h->hc;
   a.out_stride = D;
+  set_prefetch<D>(h, a, 2, l);
   if (h->attn_bucket < NBKT) {  // merge the split-S partials while staging
     static_assert(ATTN_NSP == 4 && NBKT == 8, "merge variant / bucket switch above");
     a.xin = h->part;
@@ -128,6 +160,7 @@ static int gemv_fc(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.xin = h->hc;
   a.out = h->ff;
   a.out_stride = 4 * D;
+  set_prefetch<D>(h, a, 3, l);
   return launch_gemv<WT, KVT, D, DM::R1, DM::U_FC, B, IN_LN, EPI_GELU, DM::W_FC, DM::XLDS>(a, st);
 }
 
@@ -144,6 +177,7 @@ static int gemv_pr(ixtts_gpt* h, int l, int slot0, hipStream_t st) {
   a.xin = h->ff;
   a.out = h->hc;
   a.out_stride = D;
+  set_prefetch<D>(h, a, l + 1 < h->L ? 0 : 4, l + 1);
   return launch_gemv_lds<WT, KVT, 4 * D, DM::R4, DM::U_PR, B, EPI_RESID, DM::W_PR>(a, st);
 }
 
@@ -162,6 +196,7 @@ static int gemv_head(ixtts_gpt* h, int slot0, float* norm_out, hipStream_t st) {
   a.out = h->logits;
   a.out_stride = h->V;
   a.norm_out = norm_out;
+  set_prefetch<D>(h, a, 0, 0);  // the next step's first matrix (the sampler launch in between reads no weights)
   return launch_gemv<WT, KVT, D, DM::R1, DM::U_HEAD, B, IN_LN2, EPI_LOGITS, 4, true>(a, st);
 }
 
@@ -481,6 +516,7 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   h->wide = c->max_batch > MAXB_REG;
   if (const char* e = getenv("IXTTS_WIDE")) h->wide = h->wide || (strcmp(e, "1") == 0 && c->weight_dtype == IXTTS_DTYPE_BF16);  // A/B: small batches on the MFMA GEMVs
   if (const char* e = getenv("IXTTS_BEAM_REORDER")) h->beam_every_row = strcmp(e, "full") == 0;
+  if (const char* e = getenv("IXTTS_PF_KIB")) h->pf_per = atoi(e);  // IXTTS_PF builds: KiB fetched ahead per consumer wave (0: none)
   if (h->wide) h->attn_split = false;  // one workgroup per (head, slot): see forward_layers_wide
   memset(h->host_prompt_len, 0, sizeof(h->host_prompt_len));
   memset(h->host_gen_est, 0, sizeof(h->host_gen_est));

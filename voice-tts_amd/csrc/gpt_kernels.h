@@ -94,7 +94,61 @@ struct GemvArgs {
   float* norm_out;      // optional (IN_LN2): ln_f output BEFORE the folded final_norm gain, unused
   unsigned* aux;        // EPI_QKV: fused-MLP arrival counters to clear (or null)
   float* xout;          // IN_LN_PART: where the completed residual stream is published
+  const void* pf_ptr;   // IXTTS_PF builds: the next launch's weights; consumer wave w's bytes start at pf_ptr + w * pf_stride
+  int pf_stride, pf_per, pf_nwaves;  // pf_per: KiB fetched ahead per consumer wave (<= IXTTS_PF)
 };
+
+// ---- the weight stream of the register GEMVs is loaded NON-TEMPORAL (global_load_dwordx4 ... nt): once-read bytes that then do
+// not displace the K/V rows (re-read every step: 74 MB at 600 keys) and the activations from L2 / Infinity Cache.  Measured (r03,
+// tools/step_ab.py, 1100 steps from 137 keys, tokens identical): B=1 514.6 -> 488.4 us per step, B=2 592.8 -> 577.1, B=3 667.2 ->
+// 661.0.  The wide MFMA GEMVs (gpt_wide.h) keep plain loads: nt cost them 1.6 % (B=6 754.7 -> 766.7, B=16 974.0 -> 989.7).
+// IXTTS_NT_W=0 builds the plain-load variant for the A/B.
+#ifndef IXTTS_NT_W
+#define IXTTS_NT_W 1
+#endif
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <bool NT = (IXTTS_NT_W != 0)>
+__device__ __forceinline__ uint4 load_w16(const void* p) {
+  if constexpr (NT) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  } else {
+    return *reinterpret_cast<const uint4*>(p);
+  }
+}
+// IXTTS_PF=n (A/B lever, measured and NOT adopted -- profiles/r03_notes.md): every wave of a GEMV launch also loads up to n KiB of
+// the NEXT launch's weights, issued right behind its own weight loads so that they land under its dot products, reduction and
+// epilogue; nothing uses the values, the lines stay in L2 / Infinity Cache for the consumer (wave w's first `pf_per` KiB live at
+// pf_ptr + w * pf_stride).  B=2: 592.8 -> 626.2 / 624.0 / 616.7 us per step at 1 / 2 / 4 KiB per consumer wave (4 KiB = 40 % of the
+// FC matrix fetched ahead): the extra loads cost every launch ~0.25 us, and a consumer that finds 40 % of its weights on-die is
+// only ~10 us per step faster than one that finds 10 % -- the chain is not waiting for HBM bytes.
+#ifndef IXTTS_PF
+#define IXTTS_PF 0
+#endif
+#if IXTTS_PF > 0
+#define IXTTS_PF_PARAM , const void* pf_ptr, int pf_stride, int pf_per, int pf_nwaves
+#define IXTTS_PF_ARGS(a) , (a).pf_ptr, (a).pf_stride, (a).pf_per, (a).pf_nwaves
+struct PfRegs {
+  uint4 r[IXTTS_PF];
+};
+// unconditional loads, clamped (a load under a branch rejoins with a conservative wait-for-everything, see gemv_reg_kernel)
+__device__ __forceinline__ void pf_issue(PfRegs& p, const void* ptr, int stride, int per, int nwaves, int gw, int lane) {
+  const char* base = reinterpret_cast<const char*>(ptr) + (size_t)min(gw, nwaves - 1) * stride + lane * 16;
+#pragma unroll
+  for (int j = 0; j < IXTTS_PF; ++j) p.r[j] = *reinterpret_cast<const uint4*>(base + (size_t)min(j, per - 1) * 1024);
+}
+__device__ __forceinline__ void pf_retire(const PfRegs& p) {
+#pragma unroll
+  for (int j = 0; j < IXTTS_PF; ++j) asm volatile("" ::"v"(p.r[j].x), "v"(p.r[j].y), "v"(p.r[j].z), "v"(p.r[j].w));
+}
+#define IXTTS_PF_ISSUE(gw, lane) PfRegs pf_regs; pf_issue(pf_regs, pf_ptr, pf_stride, pf_per, pf_nwaves, gw, lane); __builtin_amdgcn_sched_barrier(0)
+#define IXTTS_PF_RETIRE() pf_retire(pf_regs)
+#else
+#define IXTTS_PF_PARAM
+#define IXTTS_PF_ARGS(a)
+#define IXTTS_PF_ISSUE(gw, lane)
+#define IXTTS_PF_RETIRE()
+#endif
 
 // 16 bytes of weights per lane per load, kept RAW in registers until the dot product.
 template <typename WT>
@@ -213,7 +267,7 @@ __device__ __forceinline__ void block_sum(float (&s)[B], float* red, int wave, i
 template <typename WT, int K, int ROWS, int UNITS, int B, int INP, int EPI, typename KVT, int WPB = 4, bool XLDS = false>
 __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, const float* xin, const float* bias, float* out, int N, int slot0, int out_stride, int smax,
                                                         void* kcache, void* vcache, const int* cur_len, int heads, int nsplit,
-                                                        const float* ln_w, const float* ln_b, unsigned* aux, float* xout IXTTS_TRACE_PARAM) {
+                                                        const float* ln_w, const float* ln_b, unsigned* aux, float* xout IXTTS_PF_PARAM IXTTS_TRACE_PARAM) {
   // scalar kernel arguments (not a by-value struct): the first 16 dwords are preloaded into SGPRs at wave launch
   // (-amdgpu-kernarg-preload-count), so the first loads do not wait for a kernarg round trip
   GemvArgs a;
@@ -317,10 +371,11 @@ __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, cons
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int e = j * PER + lane * VEC;
-      wraw[u][j] = *reinterpret_cast<const uint4*>(base + (e < min(ROWS, a.N - unit_c * ROWS) * K ? e : 0));
+      wraw[u][j] = load_w16(base + (e < min(ROWS, a.N - unit_c * ROWS) * K ? e : 0));
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  IXTTS_PF_ISSUE(blockIdx.x * WPB + wave, lane);
   // ---- 4. workgroup staging: split-S merge | LayerNorm (gain/bias of the norm feeding the matrix are pre-folded) -> LDS
   if constexpr (XLDS) {
     __shared__ __attribute__((aligned(16))) float xsh[B * K];
@@ -465,6 +520,7 @@ __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, cons
     if (u == UNITS - 1) trace.mid(tot[0][0]);
     gemv_epilogue<K, ROWS, B, EPI, KVT>(a, lane, unit, tot, pre_bias[u], pre_res[u], pre_pos);
   }
+  IXTTS_PF_RETIRE();
   trace.end();
 }
 
@@ -474,7 +530,7 @@ __global__ __launch_bounds__(64 * WPB) void gemv_reg_kernel(const void* wt, cons
 template <typename WT, int K, int ROWS, int UNITS, int B, int EPI, typename KVT, int WPB = 4>
 __global__ __launch_bounds__(64 * WPB) void gemv_lds_kernel(const void* wt, const float* xin, const float* bias, float* out, int N, int slot0, int out_stride, int smax,
                                                         void* kcache, void* vcache, const int* cur_len, int heads, int nsplit,
-                                                        const float* ln_w, const float* ln_b, unsigned* aux, float* xout IXTTS_TRACE_PARAM) {
+                                                        const float* ln_w, const float* ln_b, unsigned* aux, float* xout IXTTS_PF_PARAM IXTTS_TRACE_PARAM) {
   // scalar kernel arguments (not a by-value struct): the first 16 dwords are preloaded into SGPRs at wave launch
   // (-amdgpu-kernarg-preload-count), so the first loads do not wait for a kernarg round trip
   GemvArgs a;
@@ -524,10 +580,11 @@ __global__ __launch_bounds__(64 * WPB) void gemv_lds_kernel(const void* wt, cons
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int e = j * PER + lane * VEC;
-      wraw[u][j] = *reinterpret_cast<const uint4*>(base + (e < min(ROWS, a.N - unit_c * ROWS) * K ? e : 0));
+      wraw[u][j] = load_w16(base + (e < min(ROWS, a.N - unit_c * ROWS) * K ? e : 0));
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  IXTTS_PF_ISSUE(blockIdx.x * WPB + wave, lane);
 #pragma unroll
   for (int i = 0; i < XV; ++i) {
     const int idx = threadIdx.x + i * NT;
@@ -578,6 +635,7 @@ __global__ __launch_bounds__(64 * WPB) void gemv_lds_kernel(const void* wt, cons
     if (u == UNITS - 1) trace.mid(tot[0][0]);
     gemv_epilogue<K, ROWS, B, EPI, KVT>(a, lane, unit, tot, pre_bias[u], pre_res[u], 0);
   }
+  IXTTS_PF_RETIRE();
   trace.end();
 }
 

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_wide_kernel(const bf16* __restri
     const int pk = min(c / RP, KP - 1);
     const bf16* wrow = wt + (size_t)min(row0 + (t == 0 ? 0 : RP0) + c % RP, N - 1) * K + g * 8;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) a[t][j] = *reinterpret_cast<const uint4*>(wrow + (wave + NW * min(j * KP + pk, NI - 1)) * 32);
+    for (int j = 0; j < NL; ++j) a[t][j] = load_w16<false>(wrow + (wave + NW * min(j * KP + pk, NI - 1)) * 32);
   }
   __builtin_amdgcn_sched_barrier(0);
   // ---- 4. LayerNorm of sequence c over its 16 threads (4 lanes in each of the 4 waves), in registers
