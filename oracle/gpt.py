@@ -435,8 +435,10 @@ def generate_beam_sample(oracle, embeds, mask, max_new, num_beams=3, theta=10.0,
         if done or step == max_new:
             break
         if batched:
-            idx = torch.as_tensor(ni, dtype=torch.long)
-            lg, pasts = oracle.decode_step_batch(nt, step, [(k.index_select(0, idx), v.index_select(0, idx)) for k, v in pasts], mask)
+            if list(ni) != list(range(num_beams)):  # _reorder_cache (model_v2.py:199-212); the identity permutation moves nothing
+                idx = torch.as_tensor(ni, dtype=torch.long)
+                pasts = [(k.index_select(0, idx), v.index_select(0, idx)) for k, v in pasts]
+            lg, pasts = oracle.decode_step_batch(nt, step, pasts, mask)
             logits = [lg[j] for j in range(num_beams)]
         else:
             pasts = [pasts[ni[j]] for j in range(num_beams)]
@@ -478,8 +480,10 @@ def beam_replay(oracle, embeds, mask, step_tokens, step_src, theta=10.0, tempera
         amp = [((theta if theta else 1.0) if toks[j] in set(prefix + hist[src[j]]) else 1.0) / t_ for j in range(nb)]
         rec = dict(inc=inc, kept=[v != float("-inf") for v in inc], amp=amp)
         hist = [hist[src[j]] + [toks[j]] for j in range(nb)]
-        idx = torch.as_tensor(src, dtype=torch.long)
-        lg, pasts = oracle.decode_step_batch(toks, step, [(k.index_select(0, idx), v.index_select(0, idx)) for k, v in pasts], mask)
+        if src != list(range(nb)):
+            idx = torch.as_tensor(src, dtype=torch.long)
+            pasts = [(k.index_select(0, idx), v.index_select(0, idx)) for k, v in pasts]
+        lg, pasts = oracle.decode_step_batch(toks, step, pasts, mask)
         logits = [lg[j] for j in range(nb)]
         if step in keep_logits:
             rec["logits"] = lg.clone()

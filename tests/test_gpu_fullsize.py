@@ -230,10 +230,10 @@ def test_register_gemv_b3_b4_bf16_vs_oracle(gpt_full, prompts_b34, dev, B):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # The served default at production width (infer_v2.py:598-606: num_beams=3 beam-sample, top_k 30, top_p 0.8, T 0.8, theta 10):
 # `_beam_search` (transformers_generation_utils.py:3406-3565) + `BeamSearchScorer.process` (transformers_beam_search.py:215-318)
-# + `_reorder_cache` over 24 layers x 20 heads (model_v2.py:199-212), P = 137, context 137 -> 441 (the split-S attention switches
+# + `_reorder_cache` over 24 layers x 20 heads (model_v2.py:199-212), P = 137, context 137 -> 297 (the split-S attention switches
 # its 256-key bucket at step 118).
-N_BEAM = 304
-BEAM_READS = (1, 2, 116, 117, 118, 119, 120, 121, 200, N_BEAM - 1)
+N_BEAM = 160  # (the oracle's cached step loop re-concatenates its whole past every step: its cost grows with the square of this)
+BEAM_READS = (1, 2, 116, 117, 118, 119, 120, 121, N_BEAM - 1)
 
 
 @pytest.fixture(scope="module")
@@ -281,7 +281,7 @@ def test_beam3_fp32_forced_draws_vs_oracle_full_size(gpt_full, bench_prompts, be
             for b in range(3):
                 worst_l = max(worst_l, float(np.abs(eng.read_logits(b) - ref[b]).max()) / scale)
     print(f"beam3 fp32: {N_BEAM} forced steps, {moved} with a non-identity beam_idx, beam score max|err| {worst_s:.2e}, logits rel err {worst_l:.2e}")
-    assert not done and moved >= 30  # (the K/V reorder really moved rows: 65 of 304 steps in the recorded run)
+    assert not done and moved >= 15  # (the K/V reorder really moved rows: 65 of 304 steps in a longer recorded run)
     assert worst_l <= 3e-4, worst_l
     assert ids.tolist() == seq and abs(sc - score) <= 2e-3 + 1e-4 * abs(score)
 
@@ -369,7 +369,7 @@ def test_beam3_bf16_register_engine_vs_oracle_full_size(gpt_full, bench_prompts,
     assert ids8.tolist() == rec[-1][3] and sc8 == rec[-1][4]
 
 
-N_BEAM_WIDE = 160
+N_BEAM_WIDE = 96
 
 
 def test_beam3_bf16_two_groups_wide_engine_vs_oracle_full_size(gpt_full, bench_prompts, dev):
@@ -382,7 +382,7 @@ def test_beam3_bf16_two_groups_wide_engine_vs_oracle_full_size(gpt_full, bench_p
     W, orc = gpt_full[0], gpt_full[1]
     n = N_BEAM_WIDE
     eng = GptEngine(WR.GPT_CFG, dtype="bf16", max_seq=137 + n + 64, max_batch=6, device=dev).load_state_dict(W)
-    reads = (1, 2, 60, n - 1)
+    reads = (1, 2, 50, n - 1)
     for g in range(2):
         eng.prefill(g * 3, bench_prompts[g][0], bench_prompts[g][2])
         eng.beam_begin(3, group=g, rng_stream=g)

@@ -205,6 +205,41 @@ def test_top_k_when_one_thread_holds_the_large_scores(dev):
             assert len(kept) == 128 and np.allclose(kept, 1.0 / 128, rtol=1e-5) and probs[int(ids[0])] > 0
 
 
+def test_top_k_ties_at_the_kth_value_keep_the_larger_scores_and_are_deterministic(dev):
+    """3 scores strictly above a plateau of 600 equal ones, top_k = 30: the k-th largest value IS the plateau.  HF keeps every
+    tie; the device's survivor list holds 128, so it keeps the 3 larger scores and fills up with plateau tokens LOWEST ID FIRST
+    -- the same set on every run (the pool overflows, so this takes the exact-select path of `topk_sorted_1024`)."""
+    import voice_tts_amd.weights as WR
+    from voice_tts_amd.gpt_engine import GptEngine
+
+    cfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2)
+    W = WR.make_gpt_weights(cfg, seed=5)
+    W["mel_head.weight"] = torch.zeros_like(W["mel_head.weight"])
+    g = torch.Generator().manual_seed(8)
+    bias = torch.randn(8194, generator=g) * 0.1
+    plateau = torch.randperm(8194, generator=g)[:603]
+    big, plateau = plateau[:3].tolist(), sorted(plateau[3:].tolist())
+    bias[plateau] = 4.0
+    bias[big] = torch.tensor([6.0, 5.5, 5.0])
+    W["mel_head.bias"] = bias
+    emb = torch.randn(20, 128, generator=g) * 0.5
+    eng = GptEngine(cfg, dtype="f32", max_seq=64, max_batch=1, device=dev).load_state_dict(W)
+    supports = []
+    for seed in range(4):
+        eng.prefill(0, emb, 0)
+        eng.decode(1, 1, repetition_penalty=1.0, temperature=1.0, top_k=30, top_p=1.0, do_sample=True, seed=seed)
+        probs = eng.read_probs(0)
+        supports.append(np.nonzero(probs > 0)[0].tolist())
+        ids, _ = eng.read(0)
+        assert probs[int(ids[0])] > 0
+    assert all(s == supports[0] for s in supports)
+    assert len(supports[0]) == 128 and set(big) <= set(supports[0])
+    assert sorted(set(supports[0]) - set(big)) == plateau[:125]  # lowest ids first
+    p = eng.read_probs(0)
+    z = np.exp(6.0) + np.exp(5.5) + np.exp(5.0) + 125 * np.exp(4.0)
+    assert np.allclose(p[big], np.exp([6.0, 5.5, 5.0]) / z, rtol=1e-5) and np.allclose(p[plateau[:125]], np.exp(4.0) / z, rtol=1e-5)
+
+
 def test_sampling_with_unbounded_top_k_vs_oracle(tiny_f32):
     """G8 corners generate() reaches through infer(top_k=..., top_p=...): top_k = 0 (off), top_k beyond the 128-entry survivor
     list, top_p = 1.0, a top_p that leaves only min_tokens_to_keep.  The device's processed probability vector equals the

@@ -195,3 +195,50 @@ def test_batched_requests_fail_alone(monkeypatch):
         assert any(len(b) == 3 for b in stub.batches), stub.batches  # the three really shared a batch
         assert rs["good1"].status_code == 200 and rs["good2"].status_code == 200
         assert rs["bad"].status_code == 500 and "RIFF" in rs["bad"].text
+
+
+def test_worker_warms_up_before_it_reports_healthy(monkeypatch):
+    """The lifespan runs `model.warm_up()` (one synthetic request) before the model is published: /health can only answer 200
+    afterwards; IXTTS_WARMUP=0 skips it."""
+    class Warm(StubTTS):
+        def __init__(self):
+            super().__init__()
+            self.warmed = 0
+
+        def warm_up(self):
+            self.warmed += 1
+            return 0.01
+
+    m = Warm()
+    with TestClient(create_app(lambda: m)) as c:
+        assert m.warmed == 1 and c.get("/health").status_code == 200
+    monkeypatch.setenv("IXTTS_WARMUP", "0")
+    m2 = Warm()
+    with TestClient(create_app(lambda: m2)) as c:
+        assert m2.warmed == 0 and c.get("/health").status_code == 200
+
+
+def test_unsupported_prompt_audio_is_a_client_error_and_pcm_models_skip_the_temp_file():
+    """`prompt.UnsupportedAudioError` (the built-in decoder reads RIFF/WAVE only) -> 415 naming the container; a model that
+    returns `(sr, pcm)` for `output_path=None` is served without the temporary-file round trip, same bytes on the wire."""
+    from voice_tts_amd.prompt import UnsupportedAudioError
+
+    class PcmTTS(StubTTS):
+        returns_pcm_without_path = True
+
+        def infer(self, spk_audio_prompt, text, output_path, **kw):
+            assert output_path is None
+            if text == "mp3":
+                raise UnsupportedAudioError("prompt audio is not a RIFF/WAVE stream: this build decodes WAV only")
+            return 22050, (np.arange(4410) % 100).astype(np.int16).reshape(-1, 1)
+
+    with TestClient(create_app(lambda: PcmTTS())) as c:
+        r = c.post("/tts", json={"text": "mp3", "spk_audio": HEX})
+        assert r.status_code == 415 and "WAV" in r.json()["detail"]
+        r = c.post("/tts", json={"text": "ok", "spk_audio": HEX})
+        assert r.status_code == 200
+        body = r.json()
+        raw = bytes.fromhex(body["audio_hex"])
+        assert raw[:4] == b"RIFF" and len(raw) == 44 + 2 * 4410 and abs(body["audio_length"] - 0.2) < 1e-9
+        with wave.open(io.BytesIO(raw)) as w:
+            assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 22050, 4410)

@@ -16,6 +16,8 @@ import math
 import torch
 import torch.nn.functional as F
 
+from .convs import conv1d, conv2d  # GEMM forms: no MIOpen in the request path (convs.py)
+
 COND_CFG = dict(
     model_dim=1280, input_size=1024, cond_num=32,
     condition_module=dict(output_size=512, linear_units=2048, attention_heads=8, num_blocks=6, perceiver_mult=2),
@@ -150,11 +152,11 @@ class Conditioning:
         x = x.transpose(1, 2)
         if mask is not None:
             x = x.masked_fill(~mask, 0.0)
-        x = F.glu(F.conv1d(x, W[e + "pointwise_conv1.weight"], W[e + "pointwise_conv1.bias"]), dim=1)
+        x = F.glu(conv1d(x, W[e + "pointwise_conv1.weight"], W[e + "pointwise_conv1.bias"]), dim=1)
         D = x.shape[1]
-        x = F.conv1d(x, W[e + "depthwise_conv.weight"], W[e + "depthwise_conv.bias"], padding=(k - 1) // 2, groups=D)
+        x = conv1d(x, W[e + "depthwise_conv.weight"], W[e + "depthwise_conv.bias"], padding=(k - 1) // 2, groups=D)
         x = F.silu(F.layer_norm(x.transpose(1, 2), (D,), W[e + "norm.weight"], W[e + "norm.bias"], 1e-5)).transpose(1, 2)
-        x = F.conv1d(x, W[e + "pointwise_conv2.weight"], W[e + "pointwise_conv2.bias"])
+        x = conv1d(x, W[e + "pointwise_conv2.weight"], W[e + "pointwise_conv2.bias"])
         if mask is not None:
             x = x.masked_fill(~mask, 0.0)
         return x.transpose(1, 2)
@@ -173,7 +175,7 @@ class Conditioning:
         B, T, _ = xs.shape
         D, heads = m["output_size"], m["attention_heads"]
         mask = (torch.arange(T, device=xs.device).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(1)  # ~make_pad_mask
-        x = F.relu(F.conv2d(xs.unsqueeze(1), W[prefix + "embed.conv.0.weight"], W[prefix + "embed.conv.0.bias"], stride=2))
+        x = F.relu(conv2d(xs.unsqueeze(1), W[prefix + "embed.conv.0.weight"], W[prefix + "embed.conv.0.bias"], stride=2))
         b, c, t, f = x.shape
         x = F.linear(x.transpose(1, 2).reshape(b, t, c * f), W[prefix + "embed.out.0.weight"], W[prefix + "embed.out.0.bias"])
         x = x * math.sqrt(D)

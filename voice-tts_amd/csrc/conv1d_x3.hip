@@ -158,8 +158,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_x3_kernel(ConvParams p) {
   issue_dma(0, Xq);
   load_a(a_cur, 0, 0);
   auto chunk_step = [&](int g, const uint4* __restrict__ cur, uint4* __restrict__ nxt) {
-    // own copies of chunk g have landed (they are older than the 6*MT A loads still in flight), then everybody's
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * MT) : "memory");
+    // own copies of chunk g have landed (they are older than the 6*MT A loads still in flight), then everybody's.  With a single
+    // tap the copy of chunk g was issued AFTER the chunk's only A loads (run_tap(.., 0) precedes issue_dma), so it is the
+    // youngest thing in flight: wait for everything (a transposed conv with kernel == stride; the shipped generator has none)
+    if (p.ntap >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * MT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     run_tap(cur, g, 0);
     if (g + 1 < nchunks) issue_dma(g + 1, nxt);  // the other buffer was last read in chunk g-1, which every wave left before the barrier above

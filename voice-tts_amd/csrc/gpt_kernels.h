@@ -1553,9 +1553,52 @@ __device__ __forceinline__ int topk_sorted_1024(const float (&vals)[PT], int V, 
   if (np > TOPK_POOL) {  // (workgroup-uniform) one thread holds many of the large scores: the exact select over every score instead
     __syncthreads();
     if (t == 0) sc.pool_n = 0;
-    thr = radix_kth_1024<PT, 4>(key, V, k, sc);
-    collect(SAMP_MAXK);
-    np = min(sc.pool_n, SAMP_MAXK);
+    thr = radix_kth_1024<PT, 4>(key, V, k, sc);  // the exact key of the k-th largest score
+    // Scores strictly above it (fewer than k <= SAMP_MAXK) all enter the pool, in any order -- the rank sort below orders them.
+    // Scores EQUAL to it (HF keeps every tie; the survivor list holds SAMP_MAXK) fill the rest lowest id first: positions from
+    // per-(register, wave) counts scanned in id order, not from the waves' arrival order -- the same survivors on every run.
+    bool tie[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const bool in = t + i * 1024 < V && vals[i] > -INFINITY;
+      const bool gt = in && key[i] > thr;
+      tie[i] = in && key[i] == thr;
+      const unsigned long long m = __ballot(gt);
+      if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&sc.pool_n, (int)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+        if (gt) {
+          sc.pool_v[pos] = vals[i];
+          sc.pool_i[pos] = t + i * 1024;
+        }
+      }
+      const unsigned long long mt = __ballot(tie[i]);
+      if (lane == 0) sc.hist[i * 16 + w] = (unsigned int)__popcll(mt);  // id = t + i * 1024: ascending in (i, wave, lane)
+    }
+    __syncthreads();
+    if (t == 0) {
+      unsigned int run = (unsigned int)sc.pool_n;
+      for (int c = 0; c < PT * 16; ++c) {
+        const unsigned int n = sc.hist[c];
+        sc.hist[c] = run;
+        run += n;
+      }
+      sc.pool_n = (int)min(run, (unsigned int)SAMP_MAXK);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const unsigned long long mt = __ballot(tie[i]);
+      const int pos = (int)sc.hist[i * 16 + w] + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mt >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mt, 0u));
+      if (tie[i] && pos < SAMP_MAXK) {
+        sc.pool_v[pos] = vals[i];
+        sc.pool_i[pos] = t + i * 1024;
+      }
+    }
+    __syncthreads();
+    np = sc.pool_n;
   }
   if (np == 0) return 0;
   // rank of pool element i = how many precede it: the wave's lanes hold the pool, one ballot per element and 64 of them

@@ -123,6 +123,8 @@ class Glue:
 
 
 class IndexTTS2:
+    returns_pcm_without_path = True  # infer(output_path=None) -> (22050, int16 [N, 1]) (infer_v2.py:776-783): the server skips the temp file
+
     def __init__(self, cfg_path="models/IndexTTS/config.yaml", model_dir="models/IndexTTS", use_fp16=False, device=None,
                  use_cuda_kernel=None, use_deepspeed=False, *, glue=None, gpt_state_dict=None, bigvgan_state_dict=None,
                  s2mel_state_dict=None, gpt_cfg=None, bigvgan_cfg=None, cond_cfg=None, s2mel_cfg=None, tokenizer=None,
@@ -343,6 +345,40 @@ class IndexTTS2:
         except NotImplementedError:
             return False
         return True
+
+    def warm_up(self, seconds=3.0, text="Hello, hello. One, two, three."):
+        """One synthetic request through EVERY stage (prompt side included) before the worker reports healthy: whatever a fresh
+        process pays once -- the BLAS library's code objects for the shapes of this model, the 8-step decode graphs, the
+        allocator's pools -- is paid here, at load, not by the first caller (the driver's fresh box spent 182 s in the first
+        request of r02; the reference's lifespan loads the model and serves the first request cold, server.py:28-77).  A tone +
+        noise prompt of `seconds` s at 22.05 kHz, a short text, at most 48 codes; the prompt caches are cleared afterwards.
+        Returns the wall time, or None when the model cannot synthesise (missing stages) or the attempt failed."""
+        import io as _io
+
+        if not self.ready():
+            return None
+        t0 = time.perf_counter()
+        rng = np.random.RandomState(0)
+        t = np.arange(int(seconds * 22050)) / 22050.0
+        x = 0.3 * np.sin(2 * np.pi * 140 * t) + 0.15 * np.sin(2 * np.pi * 280 * t + 1) + 0.02 * rng.randn(t.size)
+        buf = _io.BytesIO()
+        with wave.open(buf, "wb") as f:
+            f.setnchannels(1)
+            f.setsampwidth(2)
+            f.setframerate(22050)
+            f.writeframes((np.clip(x, -1, 1) * 32767).astype("<i2").tobytes())
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                self.infer(buf.getvalue(), text, None, max_mel_tokens=48)
+        except Exception as e:  # a warm-up must never keep a worker from starting
+            logger.warning(f"warm-up request failed: {e}")
+            return None
+        finally:
+            self.cache_spk_audio_prompt = self.cache_spk = self.cache_emo_audio_prompt = self.cache_emo_cond = None
+        dt = time.perf_counter() - t0
+        logger.info(f"warm-up request: {dt:.2f} seconds")
+        return dt
 
     def _builtin_emo_mix(self, emo_vector, style, use_random):
         from .prompt import emo_vector_mix

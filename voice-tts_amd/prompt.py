@@ -30,20 +30,32 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .convs import conv1d, conv2d  # GEMM forms: no MIOpen in the request path (convs.py)
+
 from .weights import fold_weight_norm
 
 
 # ===================================================================================================== audio decode
+class UnsupportedAudioError(ValueError):
+    """Speaker / emotion audio the built-in decoder cannot read.  The wire contract of this build: prompt
+    audio as a path or a byte string is RIFF/WAVE -- PCM 8/16/24/32-bit or IEEE float 32/64, any channel count and rate.
+    (The reference decodes through `librosa.load`, i.e. soundfile / audioread: mp3, flac, ogg too; those libraries are absent
+    here and nothing is fetched.)  `/tts` answers 415 for it, naming the supported container."""
+
+
 def _decode_riff(buf):
     """RIFF/WAVE bytes -> (float32 [channels, samples] in [-1, 1), sr).  PCM 8/16/24/32-bit, IEEE float 32/64, and
     WAVE_FORMAT_EXTENSIBLE wrappers of those (what `librosa.load` -> soundfile returns as float32)."""
     if len(buf) < 12 or buf[:4] != b"RIFF" or buf[8:12] != b"WAVE":
-        raise ValueError("not a RIFF/WAVE stream (other containers need a decoder library this image does not have)")
+        raise UnsupportedAudioError("prompt audio is not a RIFF/WAVE stream: this build decodes WAV only (mp3 / flac / ogg need a decoder "
+                                    "library the image does not have); send 8/16/24/32-bit PCM or 32/64-bit float WAV")
     pos, fmt, data = 12, None, None
     while pos + 8 <= len(buf):
         cid, size = buf[pos:pos + 4], struct.unpack("<I", buf[pos + 4:pos + 8])[0]
         body = buf[pos + 8:pos + 8 + size]
         if cid == b"fmt ":
+            if len(body) < 16:
+                raise UnsupportedAudioError(f"WAVE stream with a truncated fmt chunk ({len(body)} bytes, 16 needed)")
             tag, ch, sr, _, _, bits = struct.unpack("<HHIIHH", body[:16])
             if tag == 0xFFFE and len(body) >= 26:  # extensible: the real tag is the first 2 bytes of the sub-format GUID
                 tag = struct.unpack("<H", body[24:26])[0]
@@ -52,8 +64,12 @@ def _decode_riff(buf):
             data = body
         pos += 8 + size + (size & 1)
     if fmt is None or data is None:
-        raise ValueError("WAVE stream without fmt/data chunk")
+        raise UnsupportedAudioError("WAVE stream without fmt/data chunk")
     tag, ch, sr, bits = fmt
+    if ch < 1 or sr < 1:
+        raise UnsupportedAudioError(f"WAVE header with {ch} channels at {sr} Hz")
+    if (tag == 1 and bits not in (8, 16, 24, 32)) or (tag == 3 and bits not in (32, 64)):
+        raise UnsupportedAudioError(f"WAVE format tag {tag} with {bits}-bit samples is not supported (PCM 8/16/24/32, float 32/64)")
     if tag == 1:
         if bits == 8:
             x = (np.frombuffer(data, np.uint8).astype(np.float32) - 128.0) / 128.0
@@ -65,12 +81,10 @@ def _decode_riff(buf):
             x = ((v ^ 0x800000) - 0x800000).astype(np.float32) / 8388608.0
         elif bits == 32:
             x = (np.frombuffer(data[: len(data) // 4 * 4], "<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
-        else:
-            raise ValueError(f"unsupported PCM width {bits}")
     elif tag == 3:
         x = np.frombuffer(data[: len(data) // (bits // 8) * (bits // 8)], "<f4" if bits == 32 else "<f8").astype(np.float32)
     else:
-        raise ValueError(f"unsupported WAVE format tag {tag}")
+        raise UnsupportedAudioError(f"WAVE format tag {tag} is not supported (1 = PCM, 3 = IEEE float, or their EXTENSIBLE wrappers)")
     n = x.size // ch
     return x[: n * ch].reshape(n, ch).T.copy(), sr
 
@@ -167,7 +181,7 @@ def sinc_resample(wave, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.9
     shape = wave.shape
     x = wave.reshape(-1, shape[-1]).float()
     x = F.pad(x, (width, width + orig))
-    y = F.conv1d(x[:, None], kern, stride=orig).transpose(1, 2).reshape(x.shape[0], -1)
+    y = conv1d(x[:, None], kern, stride=orig).transpose(1, 2).reshape(x.shape[0], -1)
     target = int(math.ceil(new * shape[-1] / orig))
     return y[..., :target].reshape(shape[:-1] + (target,))
 
@@ -276,10 +290,10 @@ class CamPlus:
 
     def _res_block(self, x, p, stride):
         W = self.W
-        out = F.relu(self._bn(F.conv2d(x, W[p + "conv1.weight"], None, (stride, 1), 1), p + "bn1."))
-        out = self._bn(F.conv2d(out, W[p + "conv2.weight"], None, 1, 1), p + "bn2.")
+        out = F.relu(self._bn(conv2d(x, W[p + "conv1.weight"], None, (stride, 1), 1), p + "bn1."))
+        out = self._bn(conv2d(out, W[p + "conv2.weight"], None, 1, 1), p + "bn2.")
         if p + "shortcut.0.weight" in W:
-            x = self._bn(F.conv2d(x, W[p + "shortcut.0.weight"], None, (stride, 1)), p + "shortcut.1.")
+            x = self._bn(conv2d(x, W[p + "shortcut.0.weight"], None, (stride, 1)), p + "shortcut.1.")
         return F.relu(out + x)
 
     @staticmethod
@@ -292,28 +306,28 @@ class CamPlus:
         """feat [B, T, 80] (mean-normalised fbank) -> style [B, embedding_size]."""
         W = self.W
         x = feat.permute(0, 2, 1).unsqueeze(1)  # [B, 1, F, T]
-        x = F.relu(self._bn(F.conv2d(x, W["head.conv1.weight"], None, 1, 1), "head.bn1."))
+        x = F.relu(self._bn(conv2d(x, W["head.conv1.weight"], None, 1, 1), "head.bn1."))
         for layer in ("layer1", "layer2"):
             for i in range(2):
                 x = self._res_block(x, f"head.{layer}.{i}.", 2 if i == 0 else 1)
-        x = F.relu(self._bn(F.conv2d(x, W["head.conv2.weight"], None, (2, 1), 1), "head.bn2."))
+        x = F.relu(self._bn(conv2d(x, W["head.conv2.weight"], None, (2, 1), 1), "head.bn2."))
         x = x.reshape(x.shape[0], x.shape[1] * x.shape[2], x.shape[3])
-        x = F.relu(self._bn(F.conv1d(x, W["xvector.tdnn.linear.weight"], None, 2, 2), "xvector.tdnn.nonlinear.batchnorm."))
+        x = F.relu(self._bn(conv1d(x, W["xvector.tdnn.linear.weight"], None, 2, 2), "xvector.tdnn.nonlinear.batchnorm."))
         for bi, (n_layers, k, dil) in enumerate(self.BLOCKS, start=1):
             for li in range(1, n_layers + 1):
                 p = f"xvector.block{bi}.tdnnd{li}."
-                h = F.conv1d(F.relu(self._bn(x, p + "nonlinear1.batchnorm.")), W[p + "linear1.weight"])
+                h = conv1d(F.relu(self._bn(x, p + "nonlinear1.batchnorm.")), W[p + "linear1.weight"])
                 h = F.relu(self._bn(h, p + "nonlinear2.batchnorm."))
-                y = F.conv1d(h, W[p + "cam_layer.linear_local.weight"], None, 1, (k - 1) // 2 * dil, dil)
+                y = conv1d(h, W[p + "cam_layer.linear_local.weight"], None, 1, (k - 1) // 2 * dil, dil)
                 ctx = h.mean(-1, keepdim=True) + self._seg_pool(h)
-                ctx = F.relu(F.conv1d(ctx, W[p + "cam_layer.linear1.weight"], W[p + "cam_layer.linear1.bias"]))
-                gate = torch.sigmoid(F.conv1d(ctx, W[p + "cam_layer.linear2.weight"], W[p + "cam_layer.linear2.bias"]))
+                ctx = F.relu(conv1d(ctx, W[p + "cam_layer.linear1.weight"], W[p + "cam_layer.linear1.bias"]))
+                gate = torch.sigmoid(conv1d(ctx, W[p + "cam_layer.linear2.weight"], W[p + "cam_layer.linear2.bias"]))
                 x = torch.cat([x, y * gate], dim=1)
             p = f"xvector.transit{bi}."
-            x = F.conv1d(F.relu(self._bn(x, p + "nonlinear.batchnorm.")), W[p + "linear.weight"])
+            x = conv1d(F.relu(self._bn(x, p + "nonlinear.batchnorm.")), W[p + "linear.weight"])
         x = F.relu(self._bn(x, "xvector.out_nonlinear.batchnorm."))
         stats = torch.cat([x.mean(dim=-1), x.std(dim=-1, unbiased=True)], dim=-1)
-        out = F.conv1d(stats.unsqueeze(-1), W["xvector.dense.linear.weight"]).squeeze(-1)
+        out = conv1d(stats.unsqueeze(-1), W["xvector.dense.linear.weight"]).squeeze(-1)
         return self._bn(out, "xvector.dense.nonlinear.batchnorm.", affine=False)
 
 
@@ -399,11 +413,11 @@ class SemanticCodec:
     def quantize(self, x):
         """x [B, T, hidden] (normalised w2v-bert features) -> (codes [B, T] int64, S_ref [B, T, hidden])."""
         W, q = self.W, "quantizer.quantizers.0."
-        h = F.conv1d(x.transpose(1, 2), W["encoder.0.embed.weight"], W["encoder.0.embed.bias"], padding=3)
+        h = conv1d(x.transpose(1, 2), W["encoder.0.embed.weight"], W["encoder.0.embed.bias"], padding=3)
         h = F.layer_norm(h.transpose(1, 2), h.shape[1:2], W["encoder.0.norm.weight"], W["encoder.0.norm.bias"], 1e-6).transpose(1, 2)
         for i in range(self.cfg["vocos_num_layers"]):
             p = f"encoder.0.convnext.{i}."
-            r = F.conv1d(h, W[p + "dwconv.weight"], W[p + "dwconv.bias"], padding=3, groups=h.shape[1]).transpose(1, 2)
+            r = conv1d(h, W[p + "dwconv.weight"], W[p + "dwconv.bias"], padding=3, groups=h.shape[1]).transpose(1, 2)
             r = F.layer_norm(r, r.shape[-1:], W[p + "norm.weight"], W[p + "norm.bias"], 1e-6)
             r = F.linear(F.gelu(F.linear(r, W[p + "pwconv1.weight"], W[p + "pwconv1.bias"])), W[p + "pwconv2.weight"], W[p + "pwconv2.bias"])
             if p + "gamma" in W:

@@ -20,6 +20,8 @@ import os
 import torch
 import torch.nn.functional as F
 
+from .convs import conv1d  # GEMM forms: no MIOpen in the request path (convs.py)
+
 from .weights import fold_weight_norm
 
 S2MEL_CFG = dict(
@@ -321,7 +323,7 @@ class S2Mel:
     def vq2emb(self, codes):
         """codes [B, n] -> [B, n, semantic_dim] (FactorizedVectorQuantize.vq2emb, then the pipeline's transpose)."""
         emb = self.W["quantizer.codebook.weight"][codes.long()]  # [B,n,8]
-        out = F.conv1d(emb.transpose(1, 2), self.W["quantizer.out_project.weight"], self.W["quantizer.out_project.bias"])
+        out = conv1d(emb.transpose(1, 2), self.W["quantizer.out_project.weight"], self.W["quantizer.out_project.bias"])
         return out.transpose(1, 2)
 
     def length_regulator(self, x, ylens):
@@ -331,11 +333,11 @@ class S2Mel:
         T = int(ylens.max())
         x = F.interpolate(x.transpose(1, 2).contiguous(), size=T, mode="nearest")
         for i in range(self.cfg["lr_n_blocks"]):
-            x = F.conv1d(x, W[f"length_regulator.model.{3 * i}.weight"], W[f"length_regulator.model.{3 * i}.bias"], padding=1)
+            x = conv1d(x, W[f"length_regulator.model.{3 * i}.weight"], W[f"length_regulator.model.{3 * i}.bias"], padding=1)
             x = F.group_norm(x, 1, W[f"length_regulator.model.{3 * i + 1}.weight"], W[f"length_regulator.model.{3 * i + 1}.bias"], 1e-5)
             x = F.mish(x)
         n = 3 * self.cfg["lr_n_blocks"]
-        x = F.conv1d(x, W[f"length_regulator.model.{n}.weight"], W[f"length_regulator.model.{n}.bias"])
+        x = conv1d(x, W[f"length_regulator.model.{n}.weight"], W[f"length_regulator.model.{n}.bias"])
         mask = (torch.arange(T, device=x.device).unsqueeze(0) < ylens.unsqueeze(1)).unsqueeze(-1)
         return x.transpose(1, 2) * mask
 
@@ -424,9 +426,9 @@ class S2Mel:
                     acc = torch.baddbmm(acc, wj, xj) if j == 0 else acc.baddbmm_(wj, xj)
                 xin = acc
             else:
-                xin = F.conv1d(xin, W[p + f"in_layers.{i}.conv.conv.weight"], W[p + f"in_layers.{i}.conv.conv.bias"], dilation=d)
+                xin = conv1d(xin, W[p + f"in_layers.{i}.conv.conv.weight"], W[p + f"in_layers.{i}.conv.conv.bias"], dilation=d)
             acts = wn_gate(xin, g, i * 2 * Hw, Hw)
-            rs = F.conv1d(acts, W[p + f"res_skip_layers.{i}.conv.conv.weight"], W[p + f"res_skip_layers.{i}.conv.conv.bias"])
+            rs = conv1d(acts, W[p + f"res_skip_layers.{i}.conv.conv.weight"], W[p + f"res_skip_layers.{i}.conv.conv.bias"])
             if i < nl - 1:
                 x = x + rs[:, :Hw]
                 if not full:
@@ -554,7 +556,7 @@ class S2Mel:
         ss = _lin(F.silu(t1), W, e + "final_layer.adaLN_modulation.1")
         h = ln_modulate(h, ss)
         h = _lin(h, W, e + "final_layer.linear").transpose(1, 2)
-        out = F.conv1d(h, W[e + "conv2.weight"], W[e + "conv2.bias"])
+        out = conv1d(h, W[e + "conv2.weight"], W[e + "conv2.bias"])
         return out[:, :, out_from - lo:] if out_from > 0 else out
 
     def dit(self, x, prompt_x, x_lens, t, style, cond):

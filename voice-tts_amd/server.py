@@ -175,7 +175,12 @@ def create_app(model_factory=default_model_factory):
         visible = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "default"))
         logger.info(f"Worker {worker_id} (PID: {os.getpid()}) starting, GPU: {visible}")
         try:
-            state["model"] = model_factory()
+            model = model_factory()
+            # one synthetic request before /health answers 200 (IXTTS_WARMUP=0 turns it off): a fresh process pays its one-off
+            # costs (library code objects, decode graphs) here, not in the first caller's request
+            if os.environ.get("IXTTS_WARMUP", "1") != "0" and hasattr(model, "warm_up"):
+                model.warm_up()
+            state["model"] = model
             logger.info(f"Model loaded successfully on GPU: {visible}")
             slots = int(os.environ.get("IXTTS_BATCH_SLOTS", "0") or 0)
             if slots > 0 and hasattr(state["model"], "infer_many"):
@@ -263,6 +268,31 @@ def create_app(model_factory=default_model_factory):
                 rtf = inference_time / audio_length if audio_length > 0 else 0.0
                 logger.info(f"TTS completed (batched): audio_length={audio_length:.2f}s, inference_time={inference_time:.2f}s, rtf={rtf:.4f}")
                 return TTSResponse(audio_hex=buf.getvalue().hex(), audio_length=audio_length, inference_time=inference_time, rtf=rtf, text=request.text)
+            if getattr(model, "returns_pcm_without_path", False):
+                # The reference writes the waveform to a temporary file, reopens it for its length and reads it back for the hex
+                # string (server.py:375-408).  `infer(output_path=None)` hands back (22050, int16 [N, 1]) -- the same samples the
+                # file would hold -- so the RIFF container is built in memory: same bytes on the wire, no file system round trip.
+                import io
+
+                with inference_lock:  # one inference at a time per worker (server.py:25,384)
+                    res = model.infer(spk_audio_prompt=spk_audio_data, text=request.text, output_path=None,
+                                      emo_audio_prompt=emo_audio_data if emo_audio_data else None,
+                                      emo_alpha=request.emo_alpha if emo_audio_data else 1.0, emo_vector=emo_vector, verbose=False)
+                if res is None:
+                    raise RuntimeError("the text produced no speech segment")
+                sr, pcm = res
+                buf = io.BytesIO()
+                with wave.open(buf, "wb") as w:
+                    w.setnchannels(pcm.shape[1])
+                    w.setsampwidth(2)
+                    w.setframerate(sr)
+                    w.writeframes(pcm.astype("<i2").tobytes())
+                inference_time = time.time() - start
+                audio_length = pcm.shape[0] / float(sr)
+                rtf = inference_time / audio_length if audio_length > 0 else 0.0
+                audio_hex = buf.getvalue().hex()
+                logger.info(f"TTS completed: audio_length={audio_length:.2f}s, inference_time={inference_time:.2f}s, rtf={rtf:.4f}, size={len(audio_hex)//2} bytes")
+                return TTSResponse(audio_hex=audio_hex, audio_length=audio_length, inference_time=inference_time, rtf=rtf, text=request.text)
             with tempfile.NamedTemporaryFile(suffix=".wav", delete=False) as tmp:
                 output_path = tmp.name
             with inference_lock:  # one inference at a time per worker (server.py:25,384)
@@ -281,6 +311,8 @@ def create_app(model_factory=default_model_factory):
         except HTTPException:
             raise
         except Exception as e:
+            if type(e).__name__ == "UnsupportedAudioError":  # prompt.py: the built-in decoder reads RIFF/WAVE only -- the caller's input, not a server fault
+                raise HTTPException(status_code=415, detail=f"Unsupported prompt audio: {str(e)}")
             logger.error(f"TTS inference failed: {str(e)}")
             try:
                 if output_path and os.path.exists(output_path):
