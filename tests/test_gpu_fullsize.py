@@ -339,7 +339,8 @@ def _check_beam_run_against_oracle(orc, prompt, rec, logits_at, n, tag):
           f"logits rel err {worst_l:.2e}")
     assert worst_l <= 1.5e-2, worst_l
     assert kept >= 0.97 * total, (kept, total)
-    assert np.quantile(ratios, 0.95) <= 2 * 1.5e-2 and ratios.max() <= 6e-2, (np.quantile(ratios, 0.95), ratios.max())
+    # measured (r03): support 479/479 and 574/575, ratio median 1e-6, p95 1.1e-3, max 4.8e-3, logits 5.6e-3 / 6.7e-3 (register / wide)
+    assert ratios.max() <= 2 * 1.5e-2 and np.quantile(ratios, 0.95) <= 5e-3, (np.quantile(ratios, 0.95), ratios.max())
 
 
 def test_beam3_bf16_register_engine_vs_oracle_full_size(gpt_full, bench_prompts, dev):
