@@ -37,6 +37,12 @@ def _worker(rank, world, port, q):
     got = sharding.broadcast_tensor_dict(W, shapes, "cpu", src=0)
     assert [tuple(got[n].shape) for n, _ in shapes] == [s for _, s in shapes]
     glue_sum = float(sum(v.double().sum() for v in got.values()))
+    # a checkpoint's tensors, names and shapes known to rank 0 only (IndexTTS2(weight_broadcast=...)): metadata first, one packed buffer after
+    sd = {"gpt/text_embedding.weight": torch.randn(7, 4, generator=g), "s2mel/cfm.x": torch.randn(3, generator=g), "emo_matrix": torch.randn(5, 2, generator=g)} if rank == 0 else None
+    got2, meta = sharding.broadcast_state_dict(sd, "cpu", src=0, meta=dict(bcfg={"upsample_initial_channel": 64}, present=["gpt", "s2mel", "emo_matrix"]) if rank == 0 else None)
+    assert meta == dict(bcfg={"upsample_initial_channel": 64}, present=["gpt", "s2mel", "emo_matrix"])
+    assert {k: tuple(v.shape) for k, v in got2.items()} == {"gpt/text_embedding.weight": (7, 4), "s2mel/cfm.x": (3,), "emo_matrix": (5, 2)}
+    glue_sum += float(sum(v.double().sum() for v in got2.values()))
     mine = sharding.my_requests(7, rank, world)
     audio, elapsed = sharding.gather_throughput(10.0 * len(mine), 1.0 + rank)
     q.put((rank, [int(a.sum()) if a.dtype == torch.uint8 else float(a.sum()) for a in arenas] + [glue_sum], mine, audio, elapsed))

@@ -129,7 +129,7 @@ class IndexTTS2:
                  use_cuda_kernel=None, use_deepspeed=False, *, glue=None, gpt_state_dict=None, bigvgan_state_dict=None,
                  s2mel_state_dict=None, gpt_cfg=None, bigvgan_cfg=None, cond_cfg=None, s2mel_cfg=None, tokenizer=None,
                  max_seq=2048, max_frames=4096, w2v_bert=None, w2v_stats=None, semantic_codec_state_dict=None, codec_cfg=None,
-                 campplus_state_dict=None, emo_matrix=None, spk_matrix=None, emo_num=None):
+                 campplus_state_dict=None, emo_matrix=None, spk_matrix=None, emo_num=None, weight_broadcast=None):
         if device is None:
             if not torch.cuda.is_available():
                 raise RuntimeError("the HIP hot path needs a GPU (no CPU fallback); pass device='cuda:N'")
@@ -155,35 +155,41 @@ class IndexTTS2:
         self.stop_mel_token = gcfg["stop_mel_token"]
         # reference precision: fp16 GPT under use_fp16 (infer_v2.py:79,88-89); here bf16 is the throughput mode
         self.gpt = GptEngine(gcfg, dtype="bf16" if use_fp16 else "f32", max_seq=max_seq, max_batch=3, device=self.device)
-        if gpt_state_dict is None and cfg.get("gpt_checkpoint") and os.path.isfile(os.path.join(model_dir, cfg["gpt_checkpoint"])):
-            gpt_state_dict = load_gpt_checkpoint(os.path.join(model_dir, cfg["gpt_checkpoint"]))
+        # ---- weights: rank 0 (or a lone worker) reads model_dir; with `weight_broadcast=(rank, world)` (torch.distributed initialised,
+        # backend nccl = RCCL over xGMI) the other workers of the node read nothing but config.yaml / bpe.model / the w2v-bert
+        # directory: the glue tensors arrive as one packed message, the GPT and BigVGAN weights as their packed device arenas
+        # (north_star: "RCCL over xGMI only for weight broadcast at load"; the reference's workers each read the files, server.py:28-77)
+        self._bc = weight_broadcast
+        peer = weight_broadcast is not None and int(weight_broadcast[0]) != 0
+        files = dict(gpt=gpt_state_dict, bigvgan=bigvgan_state_dict, s2mel=s2mel_state_dict, codec=semantic_codec_state_dict, campplus=campplus_state_dict,
+                     emo_matrix=emo_matrix, spk_matrix=spk_matrix)
+        if not peer:
+            files, bcfg = self._read_model_dir(files, cfg, model_dir, bcfg, bigvgan_cfg is None)
+        if weight_broadcast is not None:
+            files, bcfg = self._exchange_glue(files, bcfg, peer)
+        gpt_state_dict, bigvgan_state_dict, s2mel_state_dict = files["gpt"], files["bigvgan"], files["s2mel"]
+        semantic_codec_state_dict, campplus_state_dict, emo_matrix, spk_matrix = files["codec"], files["campplus"], files["emo_matrix"], files["spk_matrix"]
         if gpt_state_dict is None:
             raise FileNotFoundError("no GPT weights: pass gpt_state_dict=... or provide model_dir/gpt_checkpoint (checkpoint.py:25-34)")
-        if bigvgan_state_dict is None:
-            # `BigVGAN.from_pretrained(cfg.vocoder.name)` (infer_v2.py:154-158, bigvgan.py:436-479) resolves a LOCAL directory holding
-            # config.json + bigvgan_generator.pt (or the checkpoint file itself); a hub name is never fetched
-            voc = str((cfg.get("vocoder") or {}).get("name", ""))
-            cands = [os.path.join(model_dir, voc, "bigvgan_generator.pt"), os.path.join(voc, "bigvgan_generator.pt"), os.path.join(model_dir, voc),
-                     os.path.join(model_dir, "bigvgan_generator.pt")]
-            for p in cands:
-                if voc or p == cands[-1]:
-                    if os.path.isfile(p):
-                        bigvgan_state_dict = load_bigvgan_checkpoint(p)
-                        cj = os.path.join(os.path.dirname(p), "config.json")
-                        if bigvgan_cfg is None and os.path.isfile(cj):
-                            import json
-
-                            h = json.load(open(cj))
-                            tup = lambda v: tuple(tup(x) for x in v) if isinstance(v, list) else v
-                            bcfg.update({k: tup(v) for k, v in h.items() if k in bcfg})
-                        break
         if bigvgan_state_dict is None:
             raise FileNotFoundError("no BigVGAN weights: pass bigvgan_state_dict=... or provide model_dir/bigvgan_generator.pt")
         if bigvgan_cfg is None and "conv_pre.weight" in bigvgan_state_dict:
             bcfg["upsample_initial_channel"] = int(bigvgan_state_dict["conv_pre.weight"].shape[0])  # the one width the tensors fix
         self.bigvgan = BigVGAN(bcfg, use_cuda_kernel=True, max_frames=max_frames, device=self.device)
-        self.gpt.load_state_dict(gpt_state_dict)
-        self.bigvgan.load_state_dict(bigvgan_state_dict)
+        if not peer:
+            self.gpt.load_state_dict(gpt_state_dict)
+            self.bigvgan.load_state_dict(bigvgan_state_dict)
+        if weight_broadcast is not None:  # the packed device arenas: one RCCL broadcast each, then `adopt_arena` on the receivers
+            from . import sharding
+            from .pipeline import arena_tensor
+
+            gp, gn = self.gpt.arena()
+            bp, bn = self.bigvgan.arena()
+            sharding.broadcast_weights([arena_tensor(gp, gn, self.device), arena_tensor(bp, bn, self.device)], src=0)
+            torch.cuda.synchronize(self.device)
+            if peer:
+                self.gpt.adopt_arena()
+                self.bigvgan.adopt_arena()
         self._engines = {}  # further engine shapes over the same device weights, by slot count (infer_many, beam groups)
         D = gcfg["model_dim"]
         self.text_embedding = gpt_state_dict["text_embedding.weight"].to(self.device, torch.float32)
@@ -221,16 +227,10 @@ class IndexTTS2:
         for k in codec_cfg:
             if k in (cfg.get("semantic_codec") or {}):
                 codec_cfg[k] = cfg["semantic_codec"][k]
-        if semantic_codec_state_dict is None and have("semantic_codec", "model.safetensors"):
-            from safetensors.torch import load_file
-
-            semantic_codec_state_dict = load_file(os.path.join(model_dir, "semantic_codec", "model.safetensors"))
         self.semantic_codec = PR.SemanticCodec(semantic_codec_state_dict, codec_cfg, self.device) if semantic_codec_state_dict is not None else None
         if self.semantic_codec is None:
             missing.append("semantic_codec/model.safetensors")
         self.s2mel = None
-        if s2mel_state_dict is None and cfg.get("s2mel_checkpoint") and have(cfg["s2mel_checkpoint"]):
-            s2mel_state_dict = load_s2mel_checkpoint(os.path.join(model_dir, cfg["s2mel_checkpoint"]))
         if s2mel_state_dict is not None:
             from .s2mel import S2MEL_CFG, S2Mel
 
@@ -253,8 +253,6 @@ class IndexTTS2:
         self.w2v_bert = w2v_bert
         if w2v_bert is None:
             missing.append("w2v-bert-2.0/ + " + str(cfg.get("w2v_stat", "wav2vec2bert_stats.pt")))
-        if campplus_state_dict is None and have("campplus_cn_common.bin"):
-            campplus_state_dict = torch.load(os.path.join(model_dir, "campplus_cn_common.bin"), map_location="cpu", weights_only=True)
         self.campplus = PR.CamPlus(campplus_state_dict, self.device) if campplus_state_dict is not None else None
         if self.campplus is None:
             missing.append("campplus_cn_common.bin")
@@ -271,8 +269,6 @@ class IndexTTS2:
         self.emo_num = list(emo_num if emo_num is not None else cfg.get("emo_num", []))
         for name, given, key in (("emo_matrix", emo_matrix, "emo_matrix"), ("spk_matrix", spk_matrix, "spk_matrix")):
             m = given
-            if m is None and cfg.get(key) and have(cfg[key]):
-                m = torch.load(os.path.join(model_dir, cfg[key]), map_location="cpu", weights_only=True)
             setattr(self, name, torch.split(m.to(self.device), self.emo_num) if m is not None and self.emo_num else None)
         # text front-end (row N4; infer_v2.py:161-165): a given tokenizer, else model_dir/<dataset.bpe_model> with the
         # reference's normaliser (needs WeText, as there), else `glue.tokenize`
@@ -293,6 +289,84 @@ class IndexTTS2:
         self.cache_spk = None
         self.cache_emo_audio_prompt = None
         self.cache_emo_cond = None
+
+    # ------------------------------------------------------------------ weights: files on rank 0, RCCL everywhere else
+    @staticmethod
+    def _read_model_dir(files, cfg, model_dir, bcfg, derive_bcfg):
+        """Whatever was not handed in as a tensor dict is read from model_dir (INTEGRATION.md layout); tensors only
+        (`weights_only=True` / safetensors).  Returns (files, bigvgan cfg)."""
+        have = lambda *parts: os.path.exists(os.path.join(model_dir, *parts))
+        if files["gpt"] is None and cfg.get("gpt_checkpoint") and os.path.isfile(os.path.join(model_dir, cfg["gpt_checkpoint"])):
+            files["gpt"] = load_gpt_checkpoint(os.path.join(model_dir, cfg["gpt_checkpoint"]))
+        if files["bigvgan"] is None:
+            # `BigVGAN.from_pretrained(cfg.vocoder.name)` (infer_v2.py:154-158, bigvgan.py:436-479) resolves a LOCAL directory holding
+            # config.json + bigvgan_generator.pt (or the checkpoint file itself); a hub name is never fetched
+            voc = str((cfg.get("vocoder") or {}).get("name", ""))
+            cands = [os.path.join(model_dir, voc, "bigvgan_generator.pt"), os.path.join(voc, "bigvgan_generator.pt"), os.path.join(model_dir, voc),
+                     os.path.join(model_dir, "bigvgan_generator.pt")]
+            for p in cands:
+                if voc or p == cands[-1]:
+                    if os.path.isfile(p):
+                        files["bigvgan"] = load_bigvgan_checkpoint(p)
+                        cj = os.path.join(os.path.dirname(p), "config.json")
+                        if derive_bcfg and os.path.isfile(cj):
+                            import json
+
+                            h = json.load(open(cj))
+                            tup = lambda v: tuple(tup(x) for x in v) if isinstance(v, list) else v
+                            bcfg.update({k: tup(v) for k, v in h.items() if k in bcfg})
+                        break
+        if files["codec"] is None and have("semantic_codec", "model.safetensors"):
+            from safetensors.torch import load_file
+
+            files["codec"] = load_file(os.path.join(model_dir, "semantic_codec", "model.safetensors"))
+        if files["s2mel"] is None and cfg.get("s2mel_checkpoint") and have(cfg["s2mel_checkpoint"]):
+            files["s2mel"] = load_s2mel_checkpoint(os.path.join(model_dir, cfg["s2mel_checkpoint"]))
+        if files["campplus"] is None and have("campplus_cn_common.bin"):
+            files["campplus"] = torch.load(os.path.join(model_dir, "campplus_cn_common.bin"), map_location="cpu", weights_only=True)
+        for key in ("emo_matrix", "spk_matrix"):
+            if files[key] is None and cfg.get(key) and have(cfg[key]):
+                files[key] = torch.load(os.path.join(model_dir, cfg[key]), map_location="cpu", weights_only=True)
+        return files, bcfg
+
+    def _exchange_glue(self, files, bcfg, peer):
+        """One packed RCCL message with every tensor that is not part of the two device arenas: the non-trunk tensors of gpt.pth
+        (text tables, speed embedding, conditioning encoders), s2mel, the semantic codec, CAM++, the emotion matrices -- plus the
+        small facts a receiver cannot derive without the files (BigVGAN's config, which dicts exist)."""
+        from . import sharding
+        from .gpt_engine import GPT_TENSOR_PREFIXES
+
+        pack, meta = None, None
+        if not peer:
+            pack = {}
+            for name in ("gpt", "bigvgan", "s2mel", "codec", "campplus"):
+                sd = files[name]
+                if sd is None:
+                    continue
+                for k, v in sd.items():
+                    if name == "gpt" and k.startswith(GPT_TENSOR_PREFIXES):
+                        continue  # the trunk travels as the packed device arena
+                    if name == "bigvgan" and k != "conv_pre.weight":
+                        continue  # (only its width is needed by the receiver's constructor; the weights travel as the arena)
+                    if torch.is_tensor(v) and v.is_floating_point():
+                        pack[f"{name}/{k}"] = v
+            for name in ("emo_matrix", "spk_matrix"):
+                if files[name] is not None:
+                    pack[name] = files[name]
+            meta = dict(bcfg=bcfg, present=[k for k, v in files.items() if v is not None])
+        recv, meta = sharding.broadcast_state_dict(pack, self.device, src=0, meta=meta)
+        if peer:
+            out = {k: None for k in files}
+            for name in meta["present"]:
+                out[name] = {} if name in ("gpt", "bigvgan", "s2mel", "codec", "campplus") else None
+            for k, v in recv.items():
+                if "/" in k:
+                    name, key = k.split("/", 1)
+                    out[name][key] = v
+                else:
+                    out[k] = v
+            return out, meta["bcfg"]
+        return files, bcfg
 
     # ------------------------------------------------------------------ helpers mirrored from the reference
     def interval_silence(self, wavs, sampling_rate=22050, interval_silence=200):

@@ -112,11 +112,44 @@ class TTSResponse(BaseModel):
     text: str
 
 
-def default_model_factory():
-    """What the reference's lifespan does (server.py:66-72), on the HIP path."""
+def broadcast_context(env=None):
+    """(rank, world, port) of the load-time weight broadcast, or None.  Opt-in: IXTTS_BROADCAST_LOAD=1 with IXTTS_WORKERS=N (the
+    gunicorn worker count; `main()` exports it) -- worker k (WORKER_ID = its 1-based age, set by `post_fork`) is rank k-1; only
+    rank 0 reads the checkpoints, the others receive them over RCCL (xGMI) from it."""
+    env = os.environ if env is None else env
+    if env.get("IXTTS_BROADCAST_LOAD", "0") != "1":
+        return None
+    try:
+        world, wid = int(env.get("IXTTS_WORKERS", "1")), int(env.get("WORKER_ID", "1"))
+    except ValueError:
+        return None
+    if world < 2 or not 1 <= wid <= world:
+        return None  # (a worker gunicorn re-forked after a crash has an age beyond the first N: it loads from the files)
+    return wid - 1, world, int(env.get("IXTTS_BROADCAST_PORT", "29617"))
+
+
+def default_model_factory(cfg_path="models/IndexTTS/config.yaml", model_dir="models/IndexTTS", **kw):
+    """What the reference's lifespan does (server.py:66-72), on the HIP path; with IXTTS_BROADCAST_LOAD=1 the workers of the node
+    form a one-shot RCCL group for the weight broadcast and dissolve it again (no steady-state collective exists)."""
     from indextts.infer_v2 import IndexTTS2
 
-    return IndexTTS2(cfg_path="models/IndexTTS/config.yaml", model_dir="models/IndexTTS", use_fp16=True, use_cuda_kernel=True, use_deepspeed=False)
+    bc = broadcast_context()
+    if bc is None:
+        return IndexTTS2(cfg_path=cfg_path, model_dir=model_dir, use_fp16=True, use_cuda_kernel=True, use_deepspeed=False, **kw)
+    import torch
+    import torch.distributed as dist
+
+    rank, world, port = bc
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = os.environ.get("IXTTS_BROADCAST_BACKEND", "nccl")  # nccl IS RCCL on ROCm (one GPU per worker: local device 0)
+    logger.info(f"Worker {rank + 1}/{world}: joining the weight broadcast group ({backend}, 127.0.0.1:{port})")
+    pg_kw = dict(device_id=torch.device("cuda:0")) if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, **pg_kw)
+    try:
+        return IndexTTS2(cfg_path=cfg_path, model_dir=model_dir, use_fp16=True, use_cuda_kernel=True, use_deepspeed=False,
+                         weight_broadcast=(rank, world), **kw)
+    finally:
+        dist.destroy_process_group()
 
 
 class RequestBatcher:
@@ -352,6 +385,7 @@ def main(argv=None):
     ap.add_argument("--log-level", type=str, default="info", choices=["critical", "error", "warning", "info", "debug", "trace"], help="Log level")
     args = ap.parse_args(argv)
     app = create_app()
+    os.environ.setdefault("IXTTS_WORKERS", str(args.workers))  # the forked workers inherit it: world size of the opt-in load broadcast
     if args.workers > 1:
         try:
             from gunicorn.app.base import BaseApplication

@@ -61,6 +61,23 @@ def broadcast_tensor_dict(W, shapes, device, src=0, group=None, rank=None):
     return out
 
 
+def broadcast_state_dict(sd, device, src=0, group=None, meta=None):
+    """A dict of float tensors whose NAMES AND SHAPES only rank `src` knows (it read them from a checkpoint): the names, shapes
+    and `meta` (any small picklable object of our own making) go first through `broadcast_object_list`, then every tensor in
+    ONE flat fp32 buffer on `device`.  The other ranks pass sd=None.  Returns ({name: view into the buffer}, meta)."""
+    import math
+
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group)
+    head = [None]
+    if rank == src:
+        head = [([(k, tuple(v.shape)) for k, v in sd.items()], meta)]
+    dist.broadcast_object_list(head, src=src, group=group)
+    shapes, meta = head[0]
+    return broadcast_tensor_dict(sd if rank == src else None, shapes, device, src=src, group=group, rank=rank), meta
+
+
 def mixed_requests(n_requests=64, lo=50, hi=400, seed=5, max_tokens_per_segment=120, codes_per_token=11):
     """BASELINE configs[3] / SURVEY 8(d) config 4: `n_requests` texts of randint(lo, hi+1) characters (seed 5), one token per
     character, split into ceil(len / 120) near-equal segments (what `split_segments` yields for unpunctuated text), 11 mel
