@@ -96,6 +96,28 @@ int ixtts_wn_gate_rows_f32(const float* a_dev, const float* g_dev, float* out_de
                            int g_offset, void* stream);
 int ixtts_reflect_halo_rows_f32(float* p_dev, int B, int T, int C, int left, int right, void* stream);
 
+/* Row N1 -- the linear layers of the s2mel DiT / WaveNet: C[M][N] (+)= A[M][K] . W[N][K]^T + bias, fp32 in and out
+ * replaces: `nn.Linear` / 1x1 and k-tap Conv1d of indextts/s2mel/modules/gpt_fast/model.py:242-326 (wqkv, wo, w1 | w3, w2),
+ *   wavenet.py:103-174 (in_layers as one row-shifted GEMM per tap, res_skip_layers), diffusion_transformer.py:186-257 (merge / skip
+ *   linears), called through torch's fp32 library GEMMs in r02.
+ * Arithmetic (csrc/gemm_x6.hip): every fp32 product as six exact bf16 MFMA partial products of three-way split operands, fp32
+ * accumulation -- fp32-quality results (tests/test_gpu_gemm_x6.py: error against fp64 no larger than the fp32 library GEMM's).
+ * Operands travel as bf16 PLANES [K/16][plane 3][k-half 2][rows_padded] of 16-byte units (eight consecutive k of one row):
+ *   ixtts_gemm_x6_pack   splits a weight matrix W [N][K] (fp32, row-major, K a multiple of 64) once, at load, into
+ *                        ixtts_gemm_x6_packed_bytes(N, K) bytes of device memory owned by the caller;
+ *   ixtts_gemm_x6_split  splits activations A [rows][K] (row stride lda floats, 16-byte aligned rows) into planes of
+ *                        ixtts_gemm_x6_rows_padded(rows) rows: (K/16) * 6 * rows_padded * 16 bytes owned by the caller;
+ *   ixtts_gemm_x6_f32    C[M][N] (row stride ldc) (+)= A[row0 .. row0 + M) . W^T + bias over planes holding rows_total rows (a
+ *                        row-shifted window of one split buffer = one tap of a k-tap Conv1d); bias_dev [N] or NULL; accumulate != 0
+ *                        adds to what C holds (torch's addmm_); tile: 0 = chosen by the fill of the 256 CUs, 2 / 3 = 256x128 /
+ *                        128x128 (A/B timing). */
+size_t ixtts_gemm_x6_packed_bytes(int N, int K);
+int ixtts_gemm_x6_pack(const float* w_dev, void* packed_dev, int N, int K, void* stream);
+long ixtts_gemm_x6_rows_padded(long rows);
+int ixtts_gemm_x6_split(const float* a_dev, long lda, void* planes_dev, long rows, int K, void* stream);
+int ixtts_gemm_x6_f32(const void* a_planes_dev, long rows_total, long row0, const void* packed_dev, const float* bias_dev, float* c_dev, long ldc,
+                      int M, int N, int K, int accumulate, int tile, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Seam 2 -- BigVGAN-v2 generator
  * replaces: `BigVGAN.__init__/remove_weight_norm/forward`

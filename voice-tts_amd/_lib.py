@@ -55,6 +55,11 @@ SYMBOLS = {
     "ixtts_wn_gate_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, _P]),
     "ixtts_wn_gate_rows_f32": (C.c_int, [_P, _P, _P, C.c_long, C.c_int, C.c_long, C.c_int, C.c_long, C.c_int, _P]),
     "ixtts_reflect_halo_rows_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ixtts_gemm_x6_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ixtts_gemm_x6_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "ixtts_gemm_x6_rows_padded": (C.c_long, [C.c_long]),
+    "ixtts_gemm_x6_split": (C.c_int, [_P, C.c_long, _P, C.c_long, C.c_int, _P]),
+    "ixtts_gemm_x6_f32": (C.c_int, [_P, C.c_long, C.c_long, _P, _P, _P, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ixtts_bigvgan_create": (C.c_int, [C.POINTER(_P), C.POINTER(BigVGANCfg)]),
     "ixtts_bigvgan_set_tensor": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int]),
     "ixtts_bigvgan_finalize": (C.c_int, [_P]),
