@@ -38,12 +38,20 @@ def test_config1_chain_at_production_width_vs_cpu_path():
     from oracle import vocoder as OV
     from voice_tts_amd.pipeline import HotPath
 
+    import time
+
+    t_ = [time.perf_counter()]
+
+    def lap(what):
+        t_.append(time.perf_counter())
+        print(f"[chain timing] {what}: {t_[-1] - t_[-2]:.1f} s", flush=True)
+
     dev = torch.device("cuda:0")
-    torch.set_num_threads(max(torch.get_num_threads(), 8))
     Wg = WR.make_gpt_weights(WR.GPT_CFG, seed=1234)
     Wc = CD.make_cond_weights(CD.COND_CFG, seed=1234)
     Ws = S2.make_s2mel_weights(S2.S2MEL_CFG, seed=1234)
     Wb = WR.make_bigvgan_weights(WR.BIGVGAN_CFG, seed=1234)
+    lap("weights")
     text, spk, ref_mel, style, pc, noise, frames = _inputs()
     assert frames == 378
     rescale = lambda cl: cl * (0.5 / cl.std().clamp_min(1e-6))  # synthetic encoder weights: keep the GPT prefix at the scale it is built for
@@ -52,17 +60,21 @@ def test_config1_chain_at_production_width_vs_cpu_path():
     cond32, emovec = CD.Conditioning(Wc, CD.COND_CFG, device="cpu").encode_prompt(spk, None, 1.0)
     orc = OG.GptOracle(Wg, WR.GPT_CFG["layers"], WR.GPT_CFG["heads"])
     cl_ref = rescale(orc.conds_latent(cond32, emovec))
+    lap("cpu conditioning")
     fake, emb_ref, mask = orc.prepare_gpt_inputs(cl_ref, text)
     assert len(mask) == 57
     ids_ref, margins, logits = OG.generate_greedy(orc, emb_ref, mask, N_CODES, return_logits=True, suppress_stop=True)
     scale = float(logits.abs().max())
+    lap("cpu greedy decode")
     lat_ref = orc.latent_pass(cl_ref, text, torch.tensor(ids_ref))
     mel_ref = S2.S2Mel(Ws, S2.S2MEL_CFG, device="cpu")(lat_ref.unsqueeze(0), torch.tensor(ids_ref).view(1, -1), torch.tensor([N_CODES]), pc, ref_mel, style,
                                                         n_timesteps=25, inference_cfg_rate=0.7, noise=noise)
+    lap("cpu latent + s2mel")
     mel_ref_c = mel_ref.clamp(-11.5, 2.0)  # (synthetic s2mel weights: keep the log-mel range the vocoder is built for -- both sides alike)
     wav_ref = OV.bigvgan_forward(mel_ref_c, Wb)
     scaled_ref = torch.clamp(32767 * wav_ref.squeeze(1), -32767.0, 32767.0)
     pcm_ref = OV.pcm16(wav_ref.squeeze(1))
+    lap("cpu bigvgan")
 
     # ---- HIP path, chained on the device
     hp = HotPath(dtype="f32", device=dev, max_batch=1, max_seq=57 + N_CODES + 64, max_frames=frames).load(Wg, Wb)
@@ -78,6 +90,7 @@ def test_config1_chain_at_production_width_vs_cpu_path():
     e_mel = (mel.cpu() - mel_ref).abs().max().item()
     scaled = hp.vocode(mel.clamp(-11.5, 2.0)).cpu()
     e_wav = (scaled - scaled_ref).abs().max().item() / 32767
+    lap("device chain (load + run)")
     print(f"config-1 chain at production width: conds_latent err {e_cl:.2e}, {len(differ)} of {N_CODES} ids differ (min oracle margin "
           f"{min(margins):.3f} of logit scale {scale:.1f}), latent err {e_lat:.2e} (max {lat_ref.abs().max().item():.2f}), mel err {e_mel:.2e} "
           f"(max {mel_ref.abs().max().item():.2f}), waveform err {e_wav:.2e} of full scale (peak {wav_ref.abs().max().item():.3f})")

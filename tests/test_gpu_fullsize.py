@@ -125,7 +125,6 @@ def _run_bench_shape(W, prompts, dtype, dev, n=N_BENCH):
 def _oracle_rows(orc, prompts, ids):
     from oracle import gpt as OG
 
-    torch.set_num_threads(max(torch.get_num_threads(), 8))
     out = []
     for (emb, mask, pad), i in zip(prompts, ids):
         rows = OG.teacher_forced_logits(orc, emb, mask, i.tolist())  # ONE causal pass over the 1237 (1217) rows
@@ -243,7 +242,6 @@ def beam_oracle_run(gpt_full, bench_prompts):
 
     W, orc = gpt_full[0], gpt_full[1]
     emb, mask, pad = bench_prompts[0]
-    torch.set_num_threads(max(torch.get_num_threads(), 8))
     tr = []
     seq, score = OG.generate_beam_sample(orc, emb, mask, N_BEAM, generator=torch.Generator().manual_seed(21), trace=tr, batched=True,
                                          suppress_stop=True, keep_logits=set(BEAM_READS))
@@ -417,7 +415,6 @@ def test_bigvgan_full_size_config5_mel(dev):
 
     W = WR.make_bigvgan_weights(WR.BIGVGAN_CFG, seed=1234)
     mel = (torch.randn(1, 80, 1000, generator=torch.Generator().manual_seed(6)) * 2 - 4).clamp(-11.5, 2)
-    torch.set_num_threads(max(torch.get_num_threads(), 8))
     ref = OV.bigvgan_forward(mel, W)
     m = BigVGAN(WR.BIGVGAN_CFG, max_frames=1024, device=dev).load_state_dict(W)
     wav = m(mel.to(dev)).cpu()

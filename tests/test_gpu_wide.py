@@ -160,7 +160,6 @@ def test_wide_engine_at_the_benchmarked_shape_vs_oracle(dev):
         eng.decode(8, k - done, repetition_penalty=10.0, suppress_stop=True)
         done = k
         got[k] = [eng.read_logits(b).copy() for b in slots]
-    torch.set_num_threads(max(torch.get_num_threads(), 8))
     for j, b in enumerate(slots):
         ids = eng.read(b)[0][:N]
         emb, mask, pad = prompts[j]
