@@ -408,12 +408,14 @@ def main():
     wl = Workload(args, hp, dev, rank, use_s2mel, use_cond)
     # What the server does before /health answers 200 (voice-tts_amd/server.py lifespan -> IndexTTS2.warm_up): one short synthetic
     # request through every stage, so that a fresh process pays its one-off costs (the BLAS library's code objects, first
-    # allocations) at LOAD.  Here: one 20-token segment, 48 codes.  Reported as `load_warmup_s`; never part of the timed region.
+    # allocations) at LOAD.  Here: ONE segment of the workload's own shape (the library picks its GEMM kernels per shape), i.e. half a
+    # request.  Reported as `load_warmup_s`; never part of the timed region.
     t_wu = time.perf_counter()
     if not args.no_load_warmup:
         acc_w = dict(wl.stage_ms)
         pr_w = wl.prompt()
-        run_request(wl, hp, pr_w, [torch.randint(2, 12000, (20,), generator=wl.g)], 48, "greedy" if args.decode in ("greedy", "sample") else args.decode, 1, acc_w)
+        run_request(wl, hp, pr_w, [torch.randint(2, 12000, (n_tok if not mixed else 100,), generator=wl.g)], n_codes if not mixed else 1100,
+                    "greedy" if args.decode in ("greedy", "sample") else args.decode, 1, acc_w)
         torch.cuda.synchronize()
         log(f"load warm-up request done in {time.perf_counter() - t_wu:.2f}s: " + ", ".join(f"{k} {v:.0f} ms" for k, v in acc_w.items()))
     t_wu = time.perf_counter() - t_wu
