@@ -114,8 +114,6 @@ struct ixtts_gpt {
   int32_t *hyp_tok = nullptr, *beam_forced = nullptr;
   float* beam_cand_v = nullptr;  // [MAXB][SAMP_MAXK] per-beam survivors of a step (gpt_beam.hip)
   int *beam_cand_i = nullptr, *beam_cand_n = nullptr;
-  bool beam_capture = false;    // the graph being captured is a beam step (wide engines: group attention)
-  bool beam_shared_kv = true;   // IXTTS_BEAM_ATTN=per-slot turns the shared-K/V group attention off (A/B)
   bool beam_every_row = false;  // IXTTS_BEAM_REORDER=full: move every generated row at each reorder (A/B test of the shared-prefix bookkeeping)
   int* beam_lcp = nullptr;  // [MAXB*MAXB] leading generated K/V rows known identical between two beams' slots, then [MAXB] first row to copy
   hipGraphExec_t beam_exec[ixtts::MAXG + 1][ixtts::NBKT + 1] = {}, beam_multi_exec[ixtts::MAXG + 1][ixtts::NBKT + 1] = {};  // per (groups, bucket)

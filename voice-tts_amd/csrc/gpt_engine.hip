@@ -338,24 +338,8 @@ static int forward_layers_wide(ixtts_gpt* h, int B, int slot0, hipStream_t st) {
   h->hc = h->h;
   for (int l = 0; l < h->L; ++l) {
     IX_TRY(wide_which<D>(h, 0, l, B, slot0, st));
-    const void* kcl = (const void*)((uint8_t*)h->kc + l * lstride);
-    const void* vcl = (const void*)((uint8_t*)h->vc + l * lstride);
-    if (h->beam_capture && h->beam_shared_kv && B == h->beam_groups * h->num_beams && slot0 == 0) {
-      // beam groups: one workgroup per (head, group), the rows the group's beams share read once (attn_decode_group_kernel)
-      const dim3 grid(h->H, 1, h->beam_groups);
-#define IX_ATTN_GROUP(NQ) \
-  hipLaunchKernelGGL((attn_decode_group_kernel<bf16, 8, 4, NQ>), grid, dim3(512), 0, st, h->q, kcl, vcl, (const int*)h->cur_len, (const int*)h->valid_from, \
-                     (const int*)h->prompt_len, (const int*)h->beam_lcp, BEAM_LCP_STRIDE, BEAM_MAX, h->smax, h->H, slot0, D, h->att)
-      switch (h->num_beams) {
-        case 2: IX_ATTN_GROUP(2); break;
-        case 3: IX_ATTN_GROUP(3); break;
-        default: IX_ATTN_GROUP(4); break;
-      }
-#undef IX_ATTN_GROUP
-    } else {
-      hipLaunchKernelGGL((attn_decode_kernel<bf16, 8, 4>), dim3(h->H, 1, B), dim3(512), 0, st, h->q, kcl, vcl, h->cur_len, h->valid_from, h->smax, h->H, slot0, D,
-                         h->att, 1 IXTTS_TRACE_ARG);
-    }
+    hipLaunchKernelGGL((attn_decode_kernel<bf16, 8, 4>), dim3(h->H, 1, B), dim3(512), 0, st, h->q, (const void*)((uint8_t*)h->kc + l * lstride),
+                       (const void*)((uint8_t*)h->vc + l * lstride), h->cur_len, h->valid_from, h->smax, h->H, slot0, D, h->att, 1 IXTTS_TRACE_ARG);
     IX_TRY(wide_which<D>(h, 1, l, B, slot0, st));
     IX_TRY(wide_which<D>(h, 2, l, B, slot0, st));
     IX_TRY(wide_which<D>(h, 3, l, B, slot0, st));
@@ -532,7 +516,6 @@ extern "C" int ixtts_gpt_create(ixtts_gpt** out, const ixtts_gpt_cfg* c) {
   h->wide = c->max_batch > MAXB_REG;
   if (const char* e = getenv("IXTTS_WIDE")) h->wide = h->wide || (strcmp(e, "1") == 0 && c->weight_dtype == IXTTS_DTYPE_BF16);  // A/B: small batches on the MFMA GEMVs
   if (const char* e = getenv("IXTTS_BEAM_REORDER")) h->beam_every_row = strcmp(e, "full") == 0;
-  if (const char* e = getenv("IXTTS_BEAM_ATTN")) h->beam_shared_kv = strcmp(e, "per-slot") != 0;  // A/B: every beam reads its own K/V copy
   if (const char* e = getenv("IXTTS_PF_KIB")) h->pf_per = atoi(e);  // IXTTS_PF builds: KiB fetched ahead per consumer wave (0: none)
   if (h->wide) h->attn_split = false;  // one workgroup per (head, slot): see forward_layers_wide
   memset(h->host_prompt_len, 0, sizeof(h->host_prompt_len));
@@ -775,9 +758,7 @@ static int build_step_graph(ixtts_gpt* h, int B, int reps, int bucket, hipGraphE
   for (int r = 0; r < reps && rc == IXTTS_OK; ++r) {
     if (beam) launch_beam_step(h, make_sampler_state(h), cs);
     else launch_sampler(h, B, cs);
-    h->beam_capture = beam;
     rc = do_forward_layers(h, B, 0, cs);
-    h->beam_capture = false;
     if (rc == IXTTS_OK) rc = do_head(h, B, 0, nullptr, cs);
   }
   hipError_t e = hipStreamEndCapture(cs, &g);

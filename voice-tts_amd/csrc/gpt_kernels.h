@@ -1129,119 +1129,6 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* q, co
   trace.end();
 }
 
-// ---- beam groups on the wide engines: the beams of a group share their K/V rows -------------------------------------------------
-// `_reorder_cache` (model_v2.py:199-212) gives every beam its own copy of the cache, and the three attention reads of a step fetch
-// mostly the same bytes: the prompt rows are identical across the beams of a group, and so are the leading generated rows two slots
-// took from a common ancestor -- beam_step_kernel keeps that count per pair of slots (`lcp`, for the K/V reorder).  One workgroup per
-// (head, GROUP): rows [valid_from, shared) are read ONCE (from the group's first slot) and scored against all NQ queries, each beam
-// then sweeps only its own rows [shared, cur_len] from its slot.  At 1237 keys a 3-beam group reads ~0.4x the bytes.
-template <typename KVT, int NW, int IT, int NQ, typename BoundsFn>
-__device__ __forceinline__ void attn_sweep_multi(SoftAcc<KVLayout<KVT>::DPL> (&st)[NQ], const KVT* kb, const KVT* vb,
-                                                 const float (&qv)[NQ][KVLayout<KVT>::DPL], int smax, int wave, int lane, BoundsFn bounds) {
-  using LY = KVLayout<KVT>;
-  constexpr int DPL = LY::DPL, LPP = LY::LPP, PPW = LY::PPW;
-  const int pg = lane / LPP;
-  int p_lo = 0, p_hi = 0;
-  bool have_bounds = false;
-  for (int base = 0;; base += NW * PPW * IT) {
-    if (have_bounds && base >= p_hi) break;
-    uint4 kr[IT], vr[IT];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int p = base + (it * NW + wave) * PPW + pg;
-      const size_t off = (size_t)min(p, smax - 1) * HD;
-      kr[it] = *reinterpret_cast<const uint4*>(kb + off);
-      vr[it] = *reinterpret_cast<const uint4*>(vb + off);
-    }
-    if (!have_bounds) {
-      bounds(p_lo, p_hi);
-      have_bounds = true;
-    }
-    bool ok[IT];
-    float kv[IT][DPL], vv[IT][DPL];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int p = base + (it * NW + wave) * PPW + pg;
-      ok[it] = (p >= p_lo) && (p < p_hi);
-      kv_unpack(kr[it], kv[it]);
-      kv_unpack(vr[it], vv[it]);
-#pragma unroll
-      for (int i = 0; i < DPL; ++i) vv[it][i] = ok[it] ? vv[it][i] : 0.f;  // speculative rows may hold NaN / Inf bit patterns
-    }
-#pragma unroll
-    for (int b = 0; b < NQ; ++b) {
-      float sc_[IT];
-      float mn = st[b].m;
-#pragma unroll
-      for (int it = 0; it < IT; ++it) {
-        float d = 0.f;
-#pragma unroll
-        for (int i = 0; i < DPL; ++i) d = fmaf(qv[b][i], kv[it][i], d);
-#pragma unroll
-        for (int o = 1; o < LPP; o <<= 1) d += __shfl_xor(d, o, 64);
-        sc_[it] = ok[it] ? d : -INFINITY;
-        mn = fmaxf(mn, sc_[it]);
-      }
-      if (mn > -INFINITY) {
-        const float sc = expf(st[b].m - mn);
-        st[b].l *= sc;
-#pragma unroll
-        for (int i = 0; i < DPL; ++i) st[b].acc[i] *= sc;
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-          const float pw = ok[it] ? expf(sc_[it] - mn) : 0.f;
-          st[b].l += pw;
-#pragma unroll
-          for (int i = 0; i < DPL; ++i) st[b].acc[i] = fmaf(pw, vv[it][i], st[b].acc[i]);
-        }
-        st[b].m = mn;
-      }
-    }
-  }
-}
-
-template <typename KVT, int NW, int IT, int NQ>
-__global__ __launch_bounds__(NW * 64) void attn_decode_group_kernel(const float* q, const void* kcache, const void* vcache, const int* cur_len,
-                                                                    const int* valid_from, const int* prompt_len, const int* lcp, int lcp_stride,
-                                                                    int lcp_dim, int smax, int heads, int slot0, int D, float* out) {
-  using LY = KVLayout<KVT>;
-  __shared__ float sm[NW][LY::LPP][2 + LY::DPL];
-  const int hh = blockIdx.x, grp = blockIdx.z, sb = slot0 + grp * NQ;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int dp = lane % LY::LPP;
-  const int cur = cur_len[sb], vf = valid_from[sb], pl = prompt_len[sb];
-  int shared_gen = 0x7fffffff;  // leading generated rows every pair of the group's slots has in common
-#pragma unroll
-  for (int i = 0; i < NQ; ++i)
-#pragma unroll
-    for (int j = 0; j < NQ; ++j)
-      if (i != j) shared_gen = min(shared_gen, lcp[grp * lcp_stride + i * lcp_dim + j]);
-  const int sh = max(vf, min(pl + max(shared_gen, 0), cur));  // rows [vf, sh) are byte-identical across the group (the newest row never is)
-  float qv[NQ][LY::DPL];
-#pragma unroll
-  for (int b = 0; b < NQ; ++b) load_q_slice<KVT>(q + (size_t)(sb + b) * D + hh * HD, dp, qv[b]);
-  SoftAcc<LY::DPL> st[NQ];
-#pragma unroll
-  for (int b = 0; b < NQ; ++b) st[b].init();
-  const size_t srow = (size_t)heads * smax * HD;  // KVT elements between two slots of a layer
-  const KVT* kb = reinterpret_cast<const KVT*>(kcache) + ((size_t)sb * heads + hh) * smax * HD + dp * LY::DPL;
-  const KVT* vb = reinterpret_cast<const KVT*>(vcache) + ((size_t)sb * heads + hh) * smax * HD + dp * LY::DPL;
-  attn_sweep_multi<KVT, NW, IT, NQ>(st, kb, vb, qv, smax, wave, lane, [&](int& lo, int& hi) {
-    lo = vf;
-    hi = sh;
-  });
-#pragma unroll
-  for (int b = 0; b < NQ; ++b) {
-    attn_sweep<KVT, NW, IT>(st[b], kb + b * srow, vb + b * srow, qv[b], smax, wave, lane, [&](int& lo, int& hi) {
-      lo = sh;
-      hi = cur + 1;
-    }, /*speculate=*/false);
-    const float o = attn_merge<KVT, NW>(st[b], sm, wave, lane);
-    if (threadIdx.x < 64) out[(size_t)(sb + b) * D + hh * HD + threadIdx.x] = o;
-    __syncthreads();  // `sm` is reused by the next beam
-  }
-}
-
 // ------------------------------------------------------------------------------------
 // Split-S single-query attention, the default decode path: grid (H, NSP, B), 4 waves.  Workgroup `sp` of a (head, slot)
 // owns the 4*PPW-key blocks sp, sp + NSP, sp + 2 NSP, ... (interleaved, so the split is balanced at every context length
