@@ -191,7 +191,9 @@ typedef struct ixtts_sampler_cfg {
   int top_k;                /* 30; 0 (or >= vocabulary) disables the filter; any value for sampling, 1..128 in beam mode;
                                "greedy" of BASELINE configs == do_sample 0 or top_k 1 */
   float top_p;              /* 0.8                                                           */
-  int do_sample;            /* 0: argmax of penalised logits; 1: multinomial after warpers   */
+  int do_sample;            /* 0: argmax of penalised logits; 1: multinomial after warpers.  Beam mode: 1 = beam-sample (the served
+                               default), 0 = beam search proper -- the joint top 2 * num_beams, the warpers do not run
+                               (transformers_generation_utils.py:1020,3520-3524) */
   int suppress_stop;        /* bench-only fixed-length mode: stop token forced to -inf       */
   uint64_t seed;            /* Philox seed for do_sample (cannot match torch's CPU stream)   */
   float typical_mass;       /* > 0: the custom TypicalLogitsWarper of `inference_speech(typical_sampling=True, typical_mass=...)`

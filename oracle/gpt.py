@@ -454,6 +454,15 @@ def generate_beam_sample(oracle, embeds, mask, max_new, num_beams=3, theta=10.0,
     return seq, score
 
 
+def generate_beam_search(oracle, embeds, mask, max_new, num_beams=3, theta=10.0, **kw):
+    """`_beam_search` with do_sample=False (generation_utils.py:3511-3524): the 2 * num_beams candidates are the TOP of the joint
+    penalised log-probabilities + beam scores (`torch.topk`, sorted); the warpers (temperature / top-k / top-p) are sampling-only
+    (generation_utils.py:1020) and do not run.  Everything else -- scorer, cache reorder, finalize -- is the loop above.
+    Pinned by tests/golden/gpt_beam_search.npz (the reference's scorer + model forward, num_beams 2 / 3 / 4)."""
+    return generate_beam_sample(oracle, embeds, mask, max_new, num_beams=num_beams, theta=theta, temperature=None, top_k=None, top_p=None,
+                                sampler=lambda flat, step: torch.topk(flat, 2 * num_beams, largest=True, sorted=True).indices, **kw)
+
+
 def beam_replay(oracle, embeds, mask, step_tokens, step_src, theta=10.0, temperature=0.8, top_k=30, top_p=0.8, stop_mel=8193,
                 start_mel=8192, suppress_stop=False, keep_logits=()):
     """A GIVEN beam-sample run (per step: the token each new beam took and the beam it continues) pushed through the oracle:

@@ -208,7 +208,19 @@ def gen_beam():
     save("gpt_beam.npz", seed=31, **out)
 
 
-def _gen_beam_case(stop_bias, rng_seed, length_penalty=0.0):
+def gen_beam_search():
+    """Beam search WITHOUT sampling (`_beam_search` with do_sample=False, transformers_generation_utils.py:3511-3524: the candidates are
+    the top 2 * num_beams of the joint scores; only the processors run, the warpers are sampling-only, :1020)."""
+    out = {}
+    for tag, bias, seed, lp, nb in (("noeos", 4.0, 81, 0.0, 3), ("mid", 30.0, 82, 0.0, 3), ("mid2", 33.0, 87, 0.0, 3), ("eos", 38.0, 83, 0.0, 3), ("lp1", 33.0, 84, 1.0, 3),
+                                    ("lp2", 30.0, 88, 2.0, 3), ("nb2", 32.0, 85, 0.0, 2), ("nb4", 32.0, 86, 0.0, 4)):
+        r = _gen_beam_case(bias, seed, lp, do_sample=False, nb=nb)
+        print(tag, "steps", r["picks"].shape[0], "done", int(r["done"]), "seq", r["sequence"].tolist())
+        out.update({f"{tag}_{k}": v for k, v in r.items()})
+    save("gpt_beam_search.npz", seed=31, **out)
+
+
+def _gen_beam_case(stop_bias, rng_seed, length_penalty=0.0, do_sample=True, nb=3):
     """3-beam beam-sample through the reference's own BeamSearchScorer (vendored text,
     transformers_beam_search.py:123-417) + HF processors + the reference model forward; draws come from a
     seeded torch.multinomial and are stored so any implementation can replay them."""
@@ -226,13 +238,15 @@ def _gen_beam_case(stop_bias, rng_seed, length_penalty=0.0):
     D = cfg["model_dim"]
     conds_latent = torch.randn(34, D, generator=g) * 0.5
     text = torch.randint(2, 200, (10,), generator=g).to(torch.int32)
-    nb, V, max_new = 3, 8194, 24
+    V, max_new = 8194, 24
     input_ids, embeds, mask = uv.prepare_gpt_inputs(conds_latent.unsqueeze(0), text.unsqueeze(0))
     P = input_ids.shape[1]
     model = uv.inference_model
     model.store_mel_emb(embeds)
     procs = [RepetitionPenaltyLogitsProcessor(10.0), TemperatureLogitsWarper(0.8), TopKLogitsWarper(30, min_tokens_to_keep=2),
              TopPLogitsWarper(0.8, min_tokens_to_keep=2)]
+    if not do_sample:
+        procs = procs[:1]
     scorer = BeamSearchScorer(batch_size=1, num_beams=nb, device="cpu", length_penalty=length_penalty, do_early_stopping=False,
                               num_beam_hyps_to_keep=1, max_length=P + max_new)
     input_ids = input_ids.repeat_interleave(nb, dim=0)
@@ -251,10 +265,13 @@ def _gen_beam_case(stop_bias, rng_seed, length_penalty=0.0):
             scores = pr(input_ids, scores)
         scores = scores + beam_scores[:, None]
         flat = scores.view(1, nb * V)
-        picks = torch.multinomial(torch.softmax(flat, -1), 2 * nb, generator=g)
-        sc = torch.gather(flat, -1, picks)
-        sc, order = torch.sort(sc, descending=True, dim=1)
-        picks = torch.gather(picks, -1, order)
+        if do_sample:
+            picks = torch.multinomial(torch.softmax(flat, -1), 2 * nb, generator=g)
+            sc = torch.gather(flat, -1, picks)
+            sc, order = torch.sort(sc, descending=True, dim=1)
+            picks = torch.gather(picks, -1, order)
+        else:
+            sc, picks = torch.topk(flat, 2 * nb, dim=1, largest=True, sorted=True)
         next_indices = torch.div(picks, V, rounding_mode="floor")
         next_tokens = picks % V
         bo = scorer.process(input_ids, sc, next_tokens, next_indices, pad_token_id=8193, eos_token_id=8193, decoder_prompt_len=P)
@@ -665,7 +682,7 @@ def gen_emotion():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["emotion", "aa", "bigvgan", "gpt", "prod", "sampler", "beam", "s2mel", "chain", "prompt", "cond", "front"]
+    which = sys.argv[1:] or ["emotion", "aa", "bigvgan", "gpt", "prod", "sampler", "beam", "beamsearch", "s2mel", "chain", "prompt", "cond", "front"]
     if "emotion" in which:
         gen_emotion()
     if "aa" in which:
@@ -680,6 +697,8 @@ if __name__ == "__main__":
         gen_sampler()
     if "beam" in which:
         gen_beam()
+    if "beamsearch" in which:
+        gen_beam_search()
     if "s2mel" in which:
         gen_s2mel()
         gen_s2mel("s2mel_hd64.npz", seed=73, n=90, Tp=70, hidden_dim=128, num_heads=2, wavenet_hidden=128, depth=3)

@@ -284,6 +284,32 @@ def test_beam3_fp32_forced_draws_vs_oracle_full_size(gpt_full, bench_prompts, be
     assert ids.tolist() == seq and abs(sc - score) <= 2e-3 + 1e-4 * abs(score)
 
 
+def test_beam_search_without_sampling_fp32_vs_oracle_full_size(gpt_full, bench_prompts, dev):
+    """Beam search proper (`do_sample=False`, num_beams=3) at production width, fp32, free-running: no draws to force -- the device's
+    joint top 6 of every step must be the oracle's (tokens and source beams exact, scores within 2e-3), across the bucket switch."""
+    import voice_tts_amd.weights as WR
+    from oracle import gpt as OG
+    from voice_tts_amd.gpt_engine import GptEngine
+
+    W, orc = gpt_full[0], gpt_full[1]
+    emb, mask, pad = bench_prompts[0]
+    n = 72
+    tr = []
+    seq, score = OG.generate_beam_search(orc, emb, mask, n, trace=tr, batched=True, suppress_stop=True)
+    eng = GptEngine(WR.GPT_CFG, dtype="f32", max_seq=137 + n + 64, max_batch=3, device=dev).load_state_dict(W)
+    eng.prefill(0, emb, pad)
+    eng.beam_begin(3)
+    moved = 0
+    for step, t in enumerate(tr, start=1):
+        eng.beam_decode(1, repetition_penalty=10.0, suppress_stop=True, do_sample=False)
+        ids, done, sc, bs, lt, src = eng.beam_read(n)
+        assert lt.tolist() == t["next_tokens"] and src.tolist() == t["next_indices"], step
+        assert np.allclose(bs, t["next_scores"], rtol=1e-4, atol=2e-3), (step, bs, t["next_scores"])
+        moved += int(src.tolist() != [0, 1, 2])
+    print(f"beam search fp32: {n} free-running steps, {moved} with a non-identity beam_idx")
+    assert ids.tolist() == seq and abs(sc - score) <= 2e-3 + 1e-4 * abs(score)
+
+
 def _beam_free_run(eng, groups, prompts, n, chunk, seed):
     """Free-running beam-sample of `groups` groups together; returns per group the per-call (tokens, src, scores) and the
     final (ids, score)."""

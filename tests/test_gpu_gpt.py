@@ -466,6 +466,43 @@ def test_beam_sample_replays_reference_trace(beam_engines, tag):
         assert done2 and ids2.tolist() == ids.tolist()
 
 
+@pytest.mark.parametrize("tag,nb", [("noeos", 3), ("mid", 3), ("mid2", 3), ("eos", 3), ("lp1", 3), ("lp2", 3), ("nb2", 2), ("nb4", 4)])
+def test_beam_search_without_sampling_walks_the_reference_trace(golden, dev, tag, nb):
+    """`num_beams > 1, do_sample=False` (`_beam_search`'s topk branch, generation_utils.py:3520-3524): the device picks its own
+    candidates -- the joint top 2 * num_beams, no warpers -- and must walk, step by step, the trace the reference's scorer + model
+    forward produced (tests/golden/gpt_beam_search.npz); then the same through `generate()`."""
+    import voice_tts_amd.weights as WR
+    from oracle import gpt as OG
+    from voice_tts_amd.gpt_engine import GptEngine
+
+    g = golden("gpt_beam_search.npz")
+    cfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2)
+    W = WR.make_gpt_weights(cfg, seed=int(g["seed"]), head_scale=50.0)
+    W["mel_head.bias"] = W["mel_head.bias"].clone()
+    W["mel_head.bias"][8193] += float(g[f"{tag}_stop_bias"])
+    orc = OG.GptOracle(W, cfg["layers"], cfg["heads"])
+    eng = GptEngine(cfg, dtype="f32", max_seq=128, max_batch=nb, device=dev).load_state_dict(W)
+    fake, embeds, mask = orc.prepare_gpt_inputs(torch.from_numpy(g[f"{tag}_conds_latent"]), g[f"{tag}_text"])
+    max_new, lp = int(g[f"{tag}_max_new"]), float(g[f"{tag}_length_penalty"])
+    eng.prefill(0, embeds, 0)
+    eng.beam_begin(nb)
+    n_steps = g[f"{tag}_picks"].shape[0]
+    for step in range(n_steps):
+        eng.beam_decode(1, repetition_penalty=10.0, length_penalty=lp, do_sample=False)
+        ids, done, score, bs, lt, src = eng.beam_read(max_new)
+        assert lt.tolist() == g[f"{tag}_next_tokens"][step].tolist(), step
+        assert src.tolist() == g[f"{tag}_next_indices"][step].tolist(), step
+        assert np.allclose(bs, g[f"{tag}_next_scores"][step], rtol=1e-4, atol=2e-3), step
+    assert done == bool(g[f"{tag}_done"])
+    assert ids.tolist() == g[f"{tag}_sequence"].tolist()
+    assert abs(score - float(g[f"{tag}_sequence_score"][0])) <= 2e-3 * max(1.0, abs(score))
+    # the generate() surface (model_v2.py:724-729 with do_sample=False, num_beams=nb)
+    eng.store_mel_emb(embeds.unsqueeze(0))
+    out = eng.generate(torch.ones(1, embeds.shape[0] + 1, dtype=torch.long), max_length=embeds.shape[0] + 1 + max_new, do_sample=False, num_beams=nb,
+                       repetition_penalty=10.0, length_penalty=lp, temperature=0.8, top_k=30, top_p=0.8)  # warper settings are ignored
+    assert out[0, embeds.shape[0] + 1:].tolist() == g[f"{tag}_sequence"].tolist()
+
+
 def test_beam_sample_free_running_and_generate_surface(beam_engines, dev):
     from oracle import gpt as OG
 

@@ -206,6 +206,33 @@ def test_beam_sample_vs_reference_scorer(golden, tag, batched):
     assert abs(score - float(g[f"{tag}_sequence_score"][0])) <= 1e-3 * max(1.0, abs(score))
 
 
+BEAM_SEARCH_TAGS = [("noeos", 3), ("mid", 3), ("mid2", 3), ("eos", 3), ("lp1", 3), ("lp2", 3), ("nb2", 2), ("nb4", 4)]
+
+
+@pytest.mark.parametrize("tag,nb", BEAM_SEARCH_TAGS)
+def test_beam_search_without_sampling_vs_reference_scorer(golden, tag, nb):
+    """`num_beams > 1, do_sample=False` (`_beam_search`'s top-k branch, generation_utils.py:3520-3524): the oracle picks its own
+    candidates (no recorded draws to replay) and must walk the trace the reference's scorer + model forward produced."""
+    g = golden("gpt_beam_search.npz")
+    cfg = WR.tiny_gpt_cfg(model_dim=128, layers=2, heads=2)
+    W = WR.make_gpt_weights(cfg, seed=int(g["seed"]), head_scale=50.0)
+    W["mel_head.bias"] = W["mel_head.bias"].clone()
+    W["mel_head.bias"][8193] += float(g[f"{tag}_stop_bias"])
+    orc = OG.GptOracle(W, cfg["layers"], cfg["heads"])
+    fake, embeds, mask = orc.prepare_gpt_inputs(torch.from_numpy(g[f"{tag}_conds_latent"]), g[f"{tag}_text"])
+    trace = []
+    seq, score = OG.generate_beam_search(orc, embeds, mask, int(g[f"{tag}_max_new"]), num_beams=nb, trace=trace, batched=True,
+                                         length_penalty=float(g[f"{tag}_length_penalty"]))
+    assert len(trace) == g[f"{tag}_picks"].shape[0]
+    for t, pk, ns, nt, ni in zip(trace, g[f"{tag}_picks"], g[f"{tag}_next_scores"], g[f"{tag}_next_tokens"], g[f"{tag}_next_indices"]):
+        assert t["picks"] == pk.tolist()
+        assert t["next_tokens"] == nt.tolist() and t["next_indices"] == ni.tolist()
+        assert np.allclose(t["next_scores"], ns, rtol=1e-4, atol=1e-3)
+    assert trace[-1]["done"] == bool(g[f"{tag}_done"])
+    assert seq == g[f"{tag}_sequence"].tolist()
+    assert abs(score - float(g[f"{tag}_sequence_score"][0])) <= 1e-3 * max(1.0, abs(score))
+
+
 def test_beam_replay_scores_the_reference_trace(golden):
     """`beam_replay` (a given run's per-step (token, source beam) pushed through the oracle -- what the bf16 production-width
     GPU test holds the device's free-running beams to) on the reference's own trace: every step's tokens were inside the

@@ -1,4 +1,5 @@
-// gpt_beam.hip -- on-device beam-sample (the served default: num_beams=3, do_sample=True).
+// gpt_beam.hip -- on-device beam-sample (the served default: num_beams=3, do_sample=True) and, with
+// do_sample == 0, beam search proper (the joint top 2 * num_beams instead of a multinomial draw).
 //
 // Restates, per decode step and without touching the host:
 //   indextts/gpt/transformers_generation_utils.py:3473-3543  log_softmax -> processors (min_tokens_to_keep = 2)
@@ -105,7 +106,10 @@ __global__ __launch_bounds__(1024) void beam_cand_kernel(BeamArgs a) {
   if (done) return;  // hypotheses complete: HF leaves the loop here; later graph replays are no-ops
   DBG_TS(1);
   const float theta = cfg.repetition_penalty;
-  const float inv_t = cfg.temperature > 0.f ? 1.0f / cfg.temperature : 1.0f;
+  // do_sample == 0: beam search proper (`_beam_search`'s topk branch, generation_utils.py:3520-3524) -- the processors run, the
+  // warpers (temperature / top-k / top-p) are sampling-only (:1020); a beam's 2 * NB best are all the joint top 2 * NB can hold
+  const bool sampling = cfg.do_sample != 0;
+  const float inv_t = sampling && cfg.temperature > 0.f ? 1.0f / cfg.temperature : 1.0f;
   {
     float mx = -INFINITY;
 #pragma unroll
@@ -136,13 +140,13 @@ __global__ __launch_bounds__(1024) void beam_cand_kernel(BeamArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < SAMP_PT; ++i) vals[i] *= inv_t;
-    const int k = min(max(cfg.top_k, 2), SAMP_MAXK);
+    const int k = sampling ? min(max(cfg.top_k, 2), SAMP_MAXK) : 2 * a.NB;
     DBG_TS(3);
     const int n = topk_sorted_1024<SAMP_PT>(vals, V, k, tk, sort_v, sort_i);
     DBG_TS(4);
     if (threadIdx.x < 64) {  // TopP (never removes the top min_tokens_to_keep = 2) and the survivors' way out, by wave 0
       float Z;
-      const int keep = topp_wave0(sort_v, n, cfg.top_p, 2, ev, qv, &Z);
+      const int keep = sampling ? topp_wave0(sort_v, n, cfg.top_p, 2, ev, qv, &Z) : n;
       const int lane = threadIdx.x;
       if (lane == 0) a.cand_n[b] = keep;
       if (lane < n) {
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(1024) void beam_step_kernel(BeamArgs a_all) {
     // joint multinomial(2*NB) without replacement == the 2*NB largest of score + Gumbel noise (p / Exp(1) top-k)
     float u = uniform01(cfg.seed + st_stream * 0xD1B54A32D192ED03ull, (unsigned int)q, (unsigned int)kstep);
     u = fminf(fmaxf(u, 1e-7f), 1.0f - 1e-7f);
-    key = score - logf(-logf(u));
+    key = cfg.do_sample ? score - logf(-logf(u)) : score;  // do_sample == 0: `torch.topk` of the joint scores, ties to the lower flat index
     j_key[q] = key;
   }
   if (t < 4) j_key[n_tot + t] = -INFINITY;  // the rank loop below reads four keys at a time

@@ -898,7 +898,9 @@ extern "C" int ixtts_gpt_beam_force_group(ixtts_gpt* h, int group, const int32_t
 static int beam_decode_impl(ixtts_gpt* h, int n_groups, int n_steps, const ixtts_sampler_cfg* sc, hipStream_t st) {
   IX_ARG(sc && n_steps >= 0, "gpt_beam_decode: bad argument");
   IX_ARG(h->num_beams >= 2, "gpt_beam_decode: call gpt_beam_begin first");
-  IX_ARG(sc->top_k >= 1 && sc->top_k <= SAMP_MAXK && sc->temperature > 0.f && sc->top_p > 0.f, "gpt_beam_decode: 1 <= top_k <= %d, positive temperature/top_p", SAMP_MAXK);
+  // do_sample == 0 is beam search proper: the warpers do not run (generation_utils.py:1020), their settings are not looked at
+  IX_ARG(!sc->do_sample || (sc->top_k >= 1 && sc->top_k <= SAMP_MAXK && sc->temperature > 0.f && sc->top_p > 0.f),
+         "gpt_beam_decode: 1 <= top_k <= %d, positive temperature/top_p", SAMP_MAXK);
   IX_ARG(h->V <= 1024 * SAMP_PT, "gpt_beam_decode: vocabulary %d exceeds the sampler tile", h->V);
   const int nb = h->num_beams;
   IX_ARG(n_groups >= 1 && n_groups <= MAXG && n_groups * nb <= h->cfg.max_batch, "gpt_beam_decode: %d groups of %d beams exceed max_batch %d", n_groups, nb, h->cfg.max_batch);

@@ -137,8 +137,9 @@ class GptEngine:
             _lib.check(_lib.lib().ixtts_gpt_beam_park_group(self._h, int(group), self._stream()), "ixtts_gpt_beam_park_group")
 
     def beam_decode(self, n_steps, repetition_penalty=10.0, temperature=0.8, top_k=30, top_p=0.8, suppress_stop=False, seed=0, typical_mass=0.0,
-                    length_penalty=0.0, groups=1):
-        sc = _lib.SamplerCfg(repetition_penalty, temperature, top_k, top_p, 1, int(suppress_stop), seed, float(typical_mass), float(length_penalty))
+                    length_penalty=0.0, groups=1, do_sample=True):
+        """`do_sample=False`: beam search proper -- the joint top 2 * num_beams instead of the multinomial draw, no warpers."""
+        sc = _lib.SamplerCfg(repetition_penalty, temperature, top_k, top_p, int(bool(do_sample)), int(suppress_stop), seed, float(typical_mass), float(length_penalty))
         self._lp = float(length_penalty)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().ixtts_gpt_beam_decode_groups(self._h, int(groups), n_steps, C.byref(sc), self._stream()), "ixtts_gpt_beam_decode_groups")
@@ -195,8 +196,8 @@ class GptEngine:
         """
         if self.cached_mel_emb is None:
             raise RuntimeError("generate(): call store_mel_emb first (model_v2.py:137)")
-        if num_beams != 1 and (num_beams > min(self.max_batch, 4) or not do_sample):
-            raise NotImplementedError("beam mode needs 2 <= num_beams <= min(max_batch, 4) and do_sample=True (beam-sample, the served configuration)")
+        if num_beams != 1 and not (2 <= num_beams <= min(self.max_batch, 4)):
+            raise NotImplementedError("beam mode needs 2 <= num_beams <= min(max_batch, 4) (beam-sample, the served configuration, or with do_sample=False beam search)")
         # the one custom processor inference_speech ever builds is TypicalLogitsWarper(mass=typical_mass) (model_v2.py:717-722):
         # it runs on the device; anything else has no kernel
         typical_mass = float(unused.pop("typical_mass", 0.0)) if unused.pop("typical_sampling", False) else 0.0
@@ -212,7 +213,7 @@ class GptEngine:
             raise NotImplementedError("num_return_sequences > 1 is built for sampling without beams, up to max_batch sequences "
                                       "(HF expands the prompt and draws independent continuations, generation_utils.py:2128-2135)")
         greedy = (not do_sample) or top_k == 1
-        if num_beams != 1 and not (1 <= top_k <= 128):
+        if num_beams != 1 and do_sample and not (1 <= top_k <= 128):
             raise NotImplementedError("beam-sample keeps at most 128 candidates per beam on the device: 1 <= top_k <= 128 (sampling without beams takes any top_k, 0 = off)")
         top_k = max(0, int(top_k))
         P = inputs.shape[1]
@@ -229,14 +230,15 @@ class GptEngine:
         max_new = max(0, min(max_new, self.max_seq - P - 2, self.cfg["max_mel_tokens"] - 1))
         self.prefill(0, emb, n_pad)
         if num_beams != 1:
-            # served default: 3-beam beam-sample (infer_v2.py:598-605,641-658)
+            # served default: 3-beam beam-sample (infer_v2.py:598-605,641-658); do_sample=False: beam search (generation_utils.py:3520-3524)
             self.beam_begin(num_beams)
             done_steps, fin = 0, False
             ids = np.zeros(0, np.int32)
             while done_steps < max_new and not fin:
                 n = min(sync_every, max_new - done_steps)
                 self.beam_decode(n, repetition_penalty=repetition_penalty, temperature=temperature, top_k=top_k, top_p=top_p,
-                                 suppress_stop=suppress_stop, seed=int(unused.get("seed", 0)), typical_mass=typical_mass, length_penalty=length_penalty)
+                                 suppress_stop=suppress_stop, seed=int(unused.get("seed", 0)), typical_mass=typical_mass, length_penalty=length_penalty,
+                                 do_sample=do_sample)
                 done_steps += n
                 ids, fin = self.beam_read(max_new)[:2]
             out = torch.cat([inputs.reshape(1, -1).to(torch.long).cpu(), torch.from_numpy(ids.astype(np.int64)).reshape(1, -1)], dim=1)
