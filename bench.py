@@ -342,6 +342,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
+    # torch sizes its CPU pool by the HOST's cores (128 threads on a GPU box whose share is 16): the host-side pieces of a request
+    # (WAV decode, resampling, feature extraction, small tensor ops) then run oversubscribed -- 50-100 ms hiccups on 2 ms operations
+    torch.set_num_threads(host_cores())  # (per rank: at most 16, IXTTS_CPU_THREADS overrides)
 
     import voice_tts_amd.weights as WR
     from voice_tts_amd import _lib, sharding

@@ -145,3 +145,37 @@ def test_wavenet_row_layout_matches_the_conv_form(dev):
     want = cpu._wavenet(x.clone(), torch.ones(2, 1, 203), t2, True)
     got = gpu._wavenet_rows(x.transpose(1, 2).contiguous().to(dev), t2.to(dev)).transpose(1, 2).cpu() + cpu.wn_out_bias[None, :, None]
     assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_tuned_gemm_winners_rekeyed_to_other_segment_lengths_keep_the_mel(dev, monkeypatch):
+    """The TunableOp results file is recorded at one segment length; `extend_tuned_gemms` re-keys its TN winners to every other
+    length (a 1806-frame segment took 202 ms on the default heuristic, 158 ms on them).  TunableOp does not look at the library's
+    status, so a solution that does not fit a length would return garbage silently (it did, through a TT entry at an odd frame
+    count): production width, frame counts of every residue mod 4 incl. odd ones -- the mel on the re-keyed winners equals the mel
+    on the default heuristic."""
+    import voice_tts_amd.s2mel as S2
+
+    m = S2.S2Mel(S2.make_s2mel_weights(S2.S2MEL_CFG, seed=1234), S2.S2MEL_CFG, device=dev)
+    if not m.tuned_gemms:
+        pytest.skip("the shipped TunableOp results were refused by this library version's validators: nothing to re-key")
+    g = torch.Generator().manual_seed(5)
+    Tref = 430
+    pc = torch.randn(1, Tref, 512, generator=g).to(dev)
+    ref_mel = (torch.randn(1, 80, Tref, generator=g) * 2 - 5).to(dev)
+    style = torch.randn(1, 192, generator=g).to(dev)
+    seen = set()
+    for n in (423, 300, 301, 302, 640, 1013):
+        T = Tref + int(n * 1.72)
+        seen.add(T % 4)
+        lat = torch.randn(1, n, 1280, generator=g).to(dev) * 0.3
+        codes = torch.randint(0, 8192, (1, n), generator=g).to(dev)
+        lens = torch.tensor([n], device=dev)
+        noise = torch.randn(1, 80, T, generator=g)
+        monkeypatch.setenv("IXTTS_TUNED_ANY_LENGTH", "0")
+        mel0 = m(lat, codes, lens, pc, ref_mel, style, n_timesteps=3, noise=noise)
+        monkeypatch.setenv("IXTTS_TUNED_ANY_LENGTH", "1")
+        mel1 = m(lat, codes, lens, pc, ref_mel, style, n_timesteps=3, noise=noise)
+        assert (T, T - 413) in S2._tuned_lengths
+        err = float((mel1 - mel0).abs().max()) / max(1.0, float(mel0.abs().max()))
+        assert err <= 1e-4, (n, T, err)
+    assert seen == {0, 1, 2, 3}

@@ -265,10 +265,55 @@ def use_tuned_gemms(path=TUNED_GEMMS):
         return False
 
 
+# The shipped results were recorded at ONE segment length (T = 430 prompt + 1892 target frames; the WaveNet head on Th = 1909 of them):
+# TunableOp keys on the exact row count, so a segment of any other length fell back to the default heuristic -- 202 ms for 1806 frames
+# against 196 ms for 2322 (tools/s2mel_scaling.py).  The winning solutions are Tensile kernels without a size-multiple requirement on
+# the row dimension (`AF0EM1_AF1EM1` in their names): the same solution serves every row count, so the entries are re-keyed per length.
+_TUNED_T0, _TUNED_TH0 = 2322, 1909
+_tuned_lengths = set()
+
+
+def extend_tuned_gemms(T, Th, path=TUNED_GEMMS):
+    """Re-key the recorded winners of the DiT / WaveNet GEMMs (rows 2T, T, 2Th, 2Th + 4, Th at the recorded length) to this segment's
+    row counts and hand them to TunableOp.  Once per distinct (T, Th); no-op when the results file was not taken."""
+    if (T, Th) in _tuned_lengths or (T, Th) == (_TUNED_T0, _TUNED_TH0):
+        return False
+    _tuned_lengths.add((T, Th))
+    import tempfile
+
+    import torch.cuda.tunable as tn
+
+    sub = {str(2 * _TUNED_T0): str(2 * T), str(_TUNED_T0): str(T), str(_TUNED_TH0): str(Th), str(2 * _TUNED_TH0): str(2 * Th),
+           str(2 * _TUNED_TH0 + 4): str(2 * Th + 4)}
+    head, rows = [], []
+    for line in open(path).read().splitlines():
+        f = line.split(",")
+        if f[0] == "Validator":
+            head.append(line)
+        elif len(f) >= 4 and f[2] != "Default" and f[0].endswith("_TN"):
+            # TN only: both operands K-contiguous with fixed leading dimensions, the row count is a plain free index.  In the TT
+            # entries the frame count is a leading dimension and the vectorised one: their solutions carry an alignment requirement
+            # (an odd T returned garbage through a re-keyed TT entry -- TunableOp does not look at the library's status)
+            toks = f[1].split("_")
+            if any(t in sub for t in toks):
+                rows.append(",".join([f[0], "_".join(sub.get(t, t) for t in toks)] + f[2:]))
+    if not rows:
+        return False
+    with tempfile.NamedTemporaryFile("w", suffix=".csv", delete=False) as fh:
+        fh.write("\n".join(head + rows) + "\n")
+    try:
+        return bool(tn.read_file(fh.name))
+    except Exception:
+        return False
+    finally:
+        os.unlink(fh.name)
+
+
 class S2Mel:
     def __init__(self, W, cfg=S2MEL_CFG, device="cpu"):
         self.cfg = dict(cfg)
         self.device = torch.device(device)
+        self.tuned_gemms = False
         if self.device.type == "cuda" and os.environ.get("IXTTS_NO_TUNED_GEMMS") != "1":
             self.tuned_gemms = use_tuned_gemms()
         W = fold_weight_norm(dict(W))
@@ -541,6 +586,8 @@ class S2Mel:
         if lo > 0:
             x_res, xt = x_res[:, lo:], xt[:, lo:]
         Th = T - lo
+        if self.tuned_gemms and os.environ.get("IXTTS_TUNED_ANY_LENGTH", "1") == "1":
+            extend_tuned_gemms(T, Th)
         x_res = F.linear(x_res, self.skipl_res, W[e + "skip_linear.bias"]) + F.linear(xt, self.skipl_x)
         h = _lin(x_res, W, e + "conv1")
         t2 = self._t_embed(t, e + "t_embedder2")

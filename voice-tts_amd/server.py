@@ -128,11 +128,35 @@ def broadcast_context(env=None):
     return wid - 1, world, int(env.get("IXTTS_BROADCAST_PORT", "29617"))
 
 
+def cap_cpu_threads(env=None):
+    """torch sizes its CPU pool by the HOST's cores; N workers on one node would each start that many threads (128 on a 16-core
+    share measured: 50-100 ms hiccups on the 2 ms host-side pieces of a request -- WAV decode, resampling, the feature extractor).
+    Each worker takes its share of what this process may use (cgroup quota / affinity), at most 16; IXTTS_CPU_THREADS overrides."""
+    import torch
+
+    env = os.environ if env is None else env
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    try:
+        workers = max(1, int(env.get("IXTTS_WORKERS", "1")))
+    except ValueError:
+        workers = 1
+    want = int(env["IXTTS_CPU_THREADS"]) if env.get("IXTTS_CPU_THREADS", "").isdigit() else min(16, max(1, n // workers))
+    torch.set_num_threads(max(1, want))
+    return torch.get_num_threads()
+
+
 def default_model_factory(cfg_path="models/IndexTTS/config.yaml", model_dir="models/IndexTTS", **kw):
     """What the reference's lifespan does (server.py:66-72), on the HIP path; with IXTTS_BROADCAST_LOAD=1 the workers of the node
     form a one-shot RCCL group for the weight broadcast and dissolve it again (no steady-state collective exists)."""
     from indextts.infer_v2 import IndexTTS2
 
+    cap_cpu_threads()
     bc = broadcast_context()
     if bc is None:
         return IndexTTS2(cfg_path=cfg_path, model_dir=model_dir, use_fp16=True, use_cuda_kernel=True, use_deepspeed=False, **kw)
