@@ -169,21 +169,39 @@ constexpr int AP_NX = AP_TILE + 2 * AA_XH;
 constexpr int AP_NS = 2 * AP_TILE + 16;
 
 
+#ifndef IXTTS_AP_NSUB
+#define IXTTS_AP_NSUB 4
+#endif
+constexpr int AP_NSUB = IXTTS_AP_NSUB;  // consecutive 256-output tiles per workgroup: tile s+1's inputs are fetched under tile s's arithmetic
+
 template <bool FAST_SIN>
 __global__ __launch_bounds__(512) void aa_snake_planes_kernel(const float* __restrict__ x, uint4* __restrict__ xp, const float* __restrict__ up12,
                                                               const float* __restrict__ down12, const float* __restrict__ log_alpha,
                                                               const float* __restrict__ log_beta, int C, int T) {
   __shared__ __attribute__((aligned(16))) float xs[8][AP_NX];
   __shared__ __attribute__((aligned(16))) float ss[8][AP_NS];
-  __shared__ __attribute__((aligned(16))) float ys[8][AP_TILE];
+  __shared__ __attribute__((aligned(16))) float ys[2][8][AP_TILE];  // (two: tile s+1's results are written while tile s's are packed)
 
   const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;  // wave r = channel r of the octet
   const int o = blockIdx.y, b = blockIdx.z;
   const int C8 = (C + 7) >> 3;
   const int c = min(o * 8 + r, C - 1);  // (an octet past the tensor's channels: its rows are written as zeros below)
   const bool live = o * 8 + r < C;
-  const int t0 = blockIdx.x * AP_TILE;
   const float* xr = x + ((size_t)b * C + c) * T;
+  constexpr int NXR = (AP_NX + 63) / 64;  // staged inputs per lane and tile
+
+  // a short-lived workgroup (one tile) spent its life waiting for its own first loads with only 2-4 workgroups per CU to hide it:
+  // a workgroup now walks AP_NSUB tiles and holds the next tile's inputs in registers while it works on the current one
+  float xn[NXR];
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int j = 0; j < NXR; ++j) {
+      const int t = min(max(t0 - AA_XH + lane + 64 * j, 0), T - 1);
+      xn[j] = xr[t];
+    }
+  };
+  const int tile0 = blockIdx.x * AP_NSUB;
+  fetch(tile0 * AP_TILE);
 
   float fu[12], fd[12];
 #pragma unroll
@@ -193,13 +211,6 @@ __global__ __launch_bounds__(512) void aa_snake_planes_kernel(const float* __res
   }
   const float a = expf(log_alpha[c]);
   const float inv_b = 1.0f / (expf(log_beta[c]) + 1e-9f);
-
-  for (int i = lane; i < AP_NX; i += 64) {
-    int t = t0 - AA_XH + i;
-    t = min(max(t, 0), T - 1);
-    xs[r][i] = xr[t];
-  }
-  __syncthreads();
   auto pair = [&](const float* xw, float& se, float& so) {
     float ue = 0.f, uo = 0.f;
 #pragma unroll
@@ -210,69 +221,91 @@ __global__ __launch_bounds__(512) void aa_snake_planes_kernel(const float* __res
     se = snake<FAST_SIN>(2.0f * ue, a, inv_b);
     so = snake<FAST_SIN>(2.0f * uo, a, inv_b);
   };
-  const bool interior = t0 >= 3 && t0 + AP_TILE + 3 <= T - 1;
-  if (interior) {
-    const int p0 = 4 * lane;
-    float X[10];
-    *reinterpret_cast<float4*>(X) = *reinterpret_cast<const float4*>(&xs[r][p0 + 4]);
-    *reinterpret_cast<float4*>(X + 4) = *reinterpret_cast<const float4*>(&xs[r][p0 + 8]);
-    *reinterpret_cast<float2*>(X + 8) = *reinterpret_cast<const float2*>(&xs[r][p0 + 12]);
-    float S[8];
+
+  for (int sub = 0; sub < AP_NSUB; ++sub) {
+    const int t0 = (tile0 + sub) * AP_TILE;
+    if (t0 >= T) break;  // (uniform)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pair(X + q, S[2 * q], S[2 * q + 1]);
-    *reinterpret_cast<float4*>(&ss[r][2 * p0]) = *reinterpret_cast<const float4*>(S);
-    *reinterpret_cast<float4*>(&ss[r][2 * p0 + 4]) = *reinterpret_cast<const float4*>(S + 4);
-    if (lane < 7) {
-      const int pr = AP_TILE + lane;
-      float xw[7], se, so;
+    for (int j = 0; j < NXR; ++j)
+      if (lane + 64 * j < AP_NX) xs[r][lane + 64 * j] = xn[j];
+    if (sub + 1 < AP_NSUB && t0 + AP_TILE < T) fetch(t0 + AP_TILE);
+    // xs[r] and ss[r] are private to wave r (a wave's LDS accesses execute in order): no workgroup barrier between the staging, the
+    // up-filter + Snake and the down-filter -- the eight waves drift apart and one's loads sit under another's arithmetic.  The one
+    // exchange between waves is the 8-channel transpose for the packed planes below.
+    const bool interior = t0 >= 3 && t0 + AP_TILE + 3 <= T - 1;
+    if (interior) {
+      const int p0 = 4 * lane;
+      float X[10];
+      *reinterpret_cast<float4*>(X) = *reinterpret_cast<const float4*>(&xs[r][p0 + 4]);
+      *reinterpret_cast<float4*>(X + 4) = *reinterpret_cast<const float4*>(&xs[r][p0 + 8]);
+      *reinterpret_cast<float2*>(X + 8) = *reinterpret_cast<const float2*>(&xs[r][p0 + 12]);
+      float S[8];
+#ifdef IXTTS_SNK_NOMATH
 #pragma unroll
-      for (int i = 0; i < 7; ++i) xw[i] = xs[r][pr + 4 + i];
-      pair(xw, se, so);
-      ss[r][2 * pr] = se;
-      ss[r][2 * pr + 1] = so;
+      for (int q = 0; q < 4; ++q) S[2 * q] = X[q + 3], S[2 * q + 1] = X[q + 3];
+#else
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pair(X + q, S[2 * q], S[2 * q + 1]);
+#endif
+      *reinterpret_cast<float4*>(&ss[r][2 * p0]) = *reinterpret_cast<const float4*>(S);
+      *reinterpret_cast<float4*>(&ss[r][2 * p0 + 4]) = *reinterpret_cast<const float4*>(S + 4);
+      if (lane < 7) {
+        const int pr = AP_TILE + lane;
+        float xw[7], se, so;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) xw[i] = xs[r][pr + 4 + i];
+        pair(xw, se, so);
+        ss[r][2 * pr] = se;
+        ss[r][2 * pr + 1] = so;
+      }
+    } else {
+      for (int pr = lane; pr < AP_TILE + 7; pr += 64) {
+        const int m = t0 - 3 + pr;
+        const int mc = min(max(m, 0), T - 1);
+        const float* xq = &xs[r][(mc - 3) - (t0 - AA_XH)];
+        float xw[7], se, so;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) xw[i] = xq[i];
+        pair(xw, se, so);
+        if (m < 0) so = se;
+        if (m > T - 1) se = so;
+        ss[r][2 * pr] = se;
+        ss[r][2 * pr + 1] = so;
+      }
     }
-  } else {
-    for (int pr = lane; pr < AP_TILE + 7; pr += 64) {
-      const int m = t0 - 3 + pr;
-      const int mc = min(max(m, 0), T - 1);
-      const float* xq = &xs[r][(mc - 3) - (t0 - AA_XH)];
-      float xw[7], se, so;
+    {
+      const int o0 = 4 * lane;
+      float S[20];
 #pragma unroll
-      for (int i = 0; i < 7; ++i) xw[i] = xq[i];
-      pair(xw, se, so);
-      if (m < 0) so = se;
-      if (m > T - 1) se = so;
-      ss[r][2 * pr] = se;
-      ss[r][2 * pr + 1] = so;
+      for (int i = 0; i < 5; ++i) *reinterpret_cast<float4*>(S + 4 * i) = *reinterpret_cast<const float4*>(&ss[r][2 * o0 + 4 * i]);
+      float acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[q] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[q] = fmaf(fd[k], S[2 * q + 1 + k], acc[q]);
+        if (!live) acc[q] = 0.f;
+      }
+      *reinterpret_cast<float4*>(&ys[sub & 1][r][o0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
-  }
-  __syncthreads();
-  {
-    const int o0 = 4 * lane;
-    float S[20];
+    __syncthreads();  // the one barrier of a tile (ys[sub & 1] is rewritten two tiles later: behind the next tile's barrier)
+    if (threadIdx.x < AP_TILE && t0 + (int)threadIdx.x < T) {
+      float v[8];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) *reinterpret_cast<float4*>(S + 4 * i) = *reinterpret_cast<const float4*>(&ss[r][2 * o0 + 4 * i]);
-    float acc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      acc[q] = 0.f;
-#pragma unroll
-      for (int k = 0; k < 12; ++k) acc[q] = fmaf(fd[k], S[2 * q + 1 + k], acc[q]);
-      if (!live) acc[q] = 0.f;
+      for (int e = 0; e < 8; ++e) v[e] = ys[sub & 1][e][threadIdx.x];
+      uint4 ph, pm, pl;
+      split8_bf16x3(v, ph, pm, pl);
+      uint4* dst = xp + ((size_t)b * 3 * C8 + o) * T + t0 + threadIdx.x;
+#ifdef IXTTS_SNK_NOSTORE
+      if (ph.x == 0x12345678u && T < 0) {
+#endif
+      dst[0] = ph;
+      dst[(size_t)C8 * T] = pm;
+      dst[(size_t)2 * C8 * T] = pl;
+#ifdef IXTTS_SNK_NOSTORE
+      }
+#endif
     }
-    *reinterpret_cast<float4*>(&ys[r][o0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  }
-  __syncthreads();
-  if (threadIdx.x < AP_TILE && t0 + (int)threadIdx.x < T) {
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = ys[e][threadIdx.x];
-    uint4 ph, pm, pl;
-    split8_bf16x3(v, ph, pm, pl);
-    uint4* dst = xp + ((size_t)b * 3 * C8 + o) * T + t0 + threadIdx.x;
-    dst[0] = ph;
-    dst[(size_t)C8 * T] = pm;
-    dst[(size_t)2 * C8 * T] = pl;
   }
 }
 
@@ -281,7 +314,7 @@ int launch_aa_snake_planes(const float* x, void* xplanes, const float* up12, con
   if (B * C == 0 || T == 0) return IXTTS_OK;
   IX_ARG(B > 0 && C > 0 && T > 0, "aa_snake_planes: bad shape B=%d C=%d T=%d", B, C, T);
   IX_ARG((C + 7) / 8 <= 65535 && B <= 65535, "aa_snake_planes: grid too large");
-  dim3 grid(ceil_div(T, AP_TILE), (C + 7) / 8, B);
+  dim3 grid(ceil_div(T, AP_TILE * AP_NSUB), (C + 7) / 8, B);
   if (fast_sin)
     hipLaunchKernelGGL(aa_snake_planes_kernel<true>, grid, dim3(512), 0, st, x, reinterpret_cast<uint4*>(xplanes), up12, down12, la, lb, C, T);
   else
