@@ -242,3 +242,23 @@ def test_unsupported_prompt_audio_is_a_client_error_and_pcm_models_skip_the_temp
         assert raw[:4] == b"RIFF" and len(raw) == 44 + 2 * 4410 and abs(body["audio_length"] - 0.2) < 1e-9
         with wave.open(io.BytesIO(raw)) as w:
             assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 22050, 4410)
+
+
+def test_worker_cpu_pool_is_the_process_share_not_the_host(monkeypatch):
+    """torch sizes its CPU pool by the host's cores; a worker takes its share of what the process may use (at most 16), split over
+    IXTTS_WORKERS, and IXTTS_CPU_THREADS overrides (server.cap_cpu_threads, called by the model factory)."""
+    import os
+
+    import torch
+
+    from voice_tts_amd import server
+
+    before = torch.get_num_threads()
+    try:
+        share = len(os.sched_getaffinity(0))
+        assert server.cap_cpu_threads({"IXTTS_WORKERS": "1"}) == min(16, share) or share > 16
+        assert server.cap_cpu_threads({"IXTTS_WORKERS": "8"}) == max(1, min(16, share // 8)) or share > 128
+        assert server.cap_cpu_threads({"IXTTS_WORKERS": "bogus", "IXTTS_CPU_THREADS": "3"}) == 3
+        assert 1 <= server.cap_cpu_threads({}) <= 16
+    finally:
+        torch.set_num_threads(before)
