@@ -56,14 +56,27 @@ def test_continuous_batching_refills_and_trims():
 
 
 def test_fixed_length_and_idle_slot_parking():
-    # one long sequence in slot 1 while slot 0 idles after a short one: the idle slot is re-parked before it overruns max_seq
-    scripts = {1: [5, STOP], 2: [7] * 200}
-    eng = ScriptedEngine(scripts, max_batch=2, max_seq=30)
+    scripts = {1: [5, STOP], 2: [7] * 200, 3: [5, STOP]}
+    eng = ScriptedEngine(scripts, max_batch=2, max_seq=64)
     got = {}
     DecodeScheduler(eng, max_batch=2, stop_token=STOP, sync_every=8).run([_seg(1, 4, rows=15), _seg(2, 20)], lambda s, ids: got.__setitem__(s.index, ids.tolist()),
                                                                           fixed_length=True)
     assert got[1] == [5, STOP, STOP, STOP] and got[2] == [7] * 20  # fixed length: nothing is trimmed
+    # the longest expected decode goes first: the 20-token segment takes slot 0 although it was submitted second
+    assert [c for c in eng.calls if c[0] == "prefill"][:2] == [("prefill", 0, 2), ("prefill", 1, 1)]
+    # one long sequence in slot 1 while slot 0 idles after a sequence that stopped early: the idle slot is re-parked before it overruns max_seq
+    eng = ScriptedEngine(scripts, max_batch=2, max_seq=30)
+    got = {}
+    DecodeScheduler(eng, max_batch=2, stop_token=STOP, sync_every=8).run([_seg(3, 22, rows=15), _seg(2, 20)], lambda s, ids: got.__setitem__(s.index, ids.tolist()))
+    assert got[3] == [5, STOP] and got[2] == [7] * 20
     assert any(c[0] == "prefill" and c[2] == 0 for c in eng.calls), "the idle slot was parked on a stub prompt"
+
+
+def test_longest_first_is_stable_and_keeps_beam_streams():
+    from voice_tts_amd.scheduler import longest_first
+
+    segs = [_seg(11, 10, rows=5), _seg(12, 30, rows=5), _seg(13, 10, rows=9), _seg(14, 10, rows=5)]
+    assert [s.index for s in longest_first(segs)] == [2, 3, 1, 4]  # cap first, then prompt rows; ties keep the submission order
 
 
 class ScriptedBeamEngine:

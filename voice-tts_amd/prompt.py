@@ -482,6 +482,12 @@ class W2vBert:
         from transformers import SeamlessM4TFeatureExtractor
 
         self.device = torch.device(device)
+        # hidden_states[layer] is the INPUT of encoder layer `layer` (the encoder appends the running state before each layer and once
+        # after the loop; no final norm): layers `layer` .. 23 never reach what is read.  The reference runs all 24 and reads [17];
+        # dropping the unread ones returns the same tensor for 17/24 of the passes (and 0.7 GB less on the device).
+        enc = getattr(model, "encoder", None)
+        if enc is not None and hasattr(enc, "layers") and len(enc.layers) > layer:
+            enc.layers = enc.layers[:layer]
         self.model = model.to(self.device).eval()
         # preprocessor_config.json of facebook/w2v-bert-2.0: 80 mel bins, stride 2, 16 kHz, padding value 1
         self.extractor = extractor if extractor is not None else SeamlessM4TFeatureExtractor(feature_size=80, num_mel_bins=80, sampling_rate=16000,

@@ -27,6 +27,14 @@ def live_stub(engine, like):
     return like[:2] * 0
 
 
+def longest_first(items, seg_of=lambda x: x):
+    """Longest expected decode first (a stable sort; equal segments keep their order): the long segments start while the queue is
+    full and the short ones fill the tail, instead of one long segment stepping alone at the end (64 mixed requests on 16 slots:
+    71 % of the slot-steps were busy in submission order).  Expected length = the cap on new tokens, then the prompt's row count
+    (codes per text token is close to constant: 11 in the bench's fixed-length mode)."""
+    return sorted(items, key=lambda it: (-int(seg_of(it).max_new), -int(seg_of(it).embeds.shape[0])))
+
+
 class DecodeScheduler:
     """Keeps the engine's decode slots busy with segments from a queue.
 
@@ -42,7 +50,7 @@ class DecodeScheduler:
     def run(self, segments, on_done, fixed_length=False, **sampler):
         """Decode every segment; `on_done(segment, ids)` is called as each finishes (ids: int32 array, stop token included
         when it was produced).  Order of completion is not the order of submission."""
-        queue = collections.deque(segments)
+        queue = collections.deque(longest_first(list(segments)))
         slots = [None] * self.max_batch  # (segment, steps issued so far)
         length = [0] * self.max_batch    # rows each slot's sequence holds (a freed slot below n_active keeps stepping)
         max_seq = getattr(self.engine, "max_seq", None)
@@ -112,7 +120,9 @@ class BeamGroupScheduler:
     def run(self, segments, on_done, fixed_length=False, **sampler):
         """Decode every segment; `on_done(segment, ids, score)` as each finishes: ids = the best hypothesis as
         `generate()` returns it (`BeamSearchScorer.finalize`: + eos when there is room)."""
-        queue = collections.deque((seg, getattr(seg, "stream", None) if getattr(seg, "stream", None) is not None else i) for i, seg in enumerate(segments))
+        # (a segment's random stream is fixed by its place in the SUBMISSION order before the queue is re-ordered: its tokens do not change)
+        queue = collections.deque(longest_first([(seg, getattr(seg, "stream", None) if getattr(seg, "stream", None) is not None else i)
+                                                 for i, seg in enumerate(segments)], seg_of=lambda it: it[0]))
         groups = [None] * self.max_groups  # [segment, steps issued]
         begun = 0                           # groups that have held a segment (fill from 0 upwards)
         eng, nb = self.engine, self.num_beams
